@@ -1,0 +1,99 @@
+/*
+ * bkcore.h -- C ABI of the MI355X (gfx950) BK-Core library, libbkcore.so.
+ *
+ * BK-Core: for a batch of tridiagonal matrices T (diagonal a[B,N], super-diagonal b[B,N-1],
+ * sub-diagonal c[B,N-1]) and a complex shift z, the diagonal of the resolvent
+ * G_ii = diag((T - zI)^-1), by the theta (prefix) / phi (suffix) three-term recurrences.
+ *
+ * Every entry point is plain C: raw device pointers, sizes, a HIP stream passed as void*.
+ * The library never allocates or frees device memory and keeps no device pointer after a call
+ * returns.  All functions return 0 on success or a negative BKCORE_E* code; nothing throws.
+ * They are re-entrant; work is enqueued on `stream` of the CURRENT device (the caller sets the
+ * device, e.g. torch.cuda.device) and the call returns without synchronising.
+ *
+ * Reference interfaces these replace are cited per function as file:line of
+ * neko-jpg/Project-ResNet-BK-An-O-N-Language-Model-Architecture.
+ */
+#ifndef BKCORE_H
+#define BKCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element type of a, b, c */
+#define BKCORE_F32 0
+#define BKCORE_BF16 1
+#define BKCORE_F16 2
+#define BKCORE_F64 3
+
+/* flags for bkcore_forward */
+#define BKCORE_FLAG_RAW 1u        /* skip the operator's input clamp / NaN sanitising: semantics of the batched
+                                     get-diag function instead of BKCoreFunction.forward */
+#define BKCORE_FLAG_PHI_EXACT 2u  /* phi recurrence uses k_{i+1} (true trailing minors) instead of the
+                                     reference's k_i (src/models/bk_core.py:165-171) */
+
+/* error codes */
+#define BKCORE_OK 0
+#define BKCORE_EINVAL (-1)   /* bad argument (null pointer, negative size, unknown dtype) */
+#define BKCORE_ETOOLONG (-2) /* N larger than bkcore_max_seq_len() */
+#define BKCORE_ELAUNCH (-3)  /* HIP launch failed; bkcore_last_hip_error() has the HIP code */
+
+/* Size in bytes of the persistent per-(device,stream) state block bkcore_forward may be given.
+ * Allocate once with device memory, zero it once, reuse it for every call on that stream. */
+#define BKCORE_STATE_BYTES 64
+
+/*
+ * Forward: G and features.
+ *
+ * Replaces, on the reference side,
+ *   - BKCoreFunction.forward                       src/models/bk_core.py:239-300  (flags = 0)
+ *   - vmapped_get_diag / get_tridiagonal_inverse_diagonal  src/models/bk_core.py:27-216  (flags = BKCORE_FLAG_RAW)
+ * i.e. the functional slot f(a, b, c, z) -> G that all of the reference's back-ends share
+ * (src/models/bk_core.py:284,288,291).
+ *
+ * a: B rows of N elements, row r at a + r*lda elements (lda = 0 broadcasts one row, as the layer's
+ *    expand()ed buffers do, src/models/resnet_bk.py:155-157); b, c likewise with N-1 elements per row.
+ *    Inner stride is 1.  in_dtype is one of BKCORE_F32/BF16/F16/F64 and applies to all three.
+ * z: either z_dev != NULL (device pointer to 2 floats: re, im -- no host sync needed when z is a
+ *    device tensor, src/models/resnet_bk.py:159-161) or the host values z_re, z_im.
+ * G: B*N interleaved (re, im) float pairs = complex64, row-major.  Required.
+ * features: B*N*2 floats, the same numbers as G (src/models/bk_core.py:296-298), or NULL to skip.
+ * state: BKCORE_STATE_BYTES of zero-initialised persistent device memory, or NULL.  It is used only to
+ *    reproduce one corner of the reference's sanitiser without a host sync: NaNs in b or c are replaced
+ *    by 1 only when he_diag holds a NaN somewhere in the batch (src/models/bk_core.py:260-264).  With
+ *    state == NULL NaNs in b/c are never replaced (such rows then come out as zeros, as in the reference
+ *    when he_diag is clean).
+ */
+int bkcore_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc, int in_dtype,
+                   const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
+                   void *state, unsigned flags, void *stream);
+
+/*
+ * Backward, reference mode: grad_he_diag = (1-alpha) * -Re(conj(g) G^2) + alpha * -Re(conj(g)/G^2) with the
+ * reference's stabilisers, where g = grad_features[...,0] + i grad_features[...,1] (+ grad_G).
+ * Replaces BKCoreFunction.backward, src/models/bk_core.py:303-385.  alpha is BKCoreFunction.GRAD_BLEND read by
+ * the caller at backward time.
+ *
+ * G: n complex64 saved by forward; grad_features: n*2 floats or NULL; grad_G: n complex64 or NULL;
+ * grad_a: n floats (float32, src/models/bk_core.py:382).  n = B*N.
+ */
+int bkcore_backward_ref(const float *G, const float *grad_features, const float *grad_G, float alpha, int64_t n,
+                        float *grad_a, void *stream);
+
+/* Largest N bkcore_forward accepts. */
+int64_t bkcore_max_seq_len(void);
+/* HIP error code of the last failed launch on this thread (0 if none). */
+int bkcore_last_hip_error(void);
+/* Static description of an error code returned by this library. */
+const char *bkcore_error_string(int code);
+/* ABI version, bumped on any signature change. */
+int bkcore_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BKCORE_H */

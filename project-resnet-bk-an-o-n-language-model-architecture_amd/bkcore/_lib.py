@@ -1,0 +1,54 @@
+"""ctypes loader of libbkcore.so (the HIP kernels behind the C ABI declared in include/bkcore.h).
+
+There is no CPU fallback: if the shared library is missing or does not export the expected
+symbols, importing the operator fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbkcore.so")
+
+F32, BF16, F16, F64 = 0, 1, 2, 3
+FLAG_RAW = 1
+FLAG_PHI_EXACT = 2
+STATE_BYTES = 64
+ABI_VERSION = 1
+
+EXPORTS = ("bkcore_forward", "bkcore_backward_ref", "bkcore_max_seq_len", "bkcore_last_hip_error",
+           "bkcore_error_string", "bkcore_abi_version")
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"bkcore: {LIB_PATH} not found. Build it with `make -C <package>/csrc` (hipcc --offload-arch=gfx950); "
+            "there is no CPU fallback for this operator.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i64, i32, f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+    L.bkcore_forward.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp, f32, f32, i64, i64, vp, vp, vp,
+                                 ctypes.c_uint, vp]
+    L.bkcore_forward.restype = i32
+    L.bkcore_backward_ref.argtypes = [vp, vp, vp, f32, i64, vp, vp]
+    L.bkcore_backward_ref.restype = i32
+    L.bkcore_max_seq_len.restype = i64
+    L.bkcore_last_hip_error.restype = i32
+    L.bkcore_error_string.argtypes = [i32]
+    L.bkcore_error_string.restype = ctypes.c_char_p
+    L.bkcore_abi_version.restype = i32
+    if L.bkcore_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"bkcore: ABI version mismatch (library {L.bkcore_abi_version()}, wrapper {ABI_VERSION})")
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        L = load()
+        msg = L.bkcore_error_string(rc).decode()
+        raise RuntimeError(f"bkcore: {what} failed: {msg} (code {rc}, hip error {L.bkcore_last_hip_error()})")

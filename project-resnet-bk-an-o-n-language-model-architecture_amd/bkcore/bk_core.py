@@ -1,0 +1,203 @@
+"""BK-Core operator for MI355X: drop-in for the reference's ``src/models/bk_core.py``.
+
+Same names, argument meaning and return values as the reference:
+
+  * ``get_tridiagonal_inverse_diagonal(a, b, c, z)``          reference bk_core.py:27-210
+  * ``vmapped_get_diag(a, b, c, z)``                           reference bk_core.py:214-216
+  * ``BKCoreFunction.apply(he_diag, h0_super, h0_sub, z, use_triton=None, use_parallel_scan=None)
+        -> (features (B,N,2) float32, G_ii (B,N) complex64)``  reference bk_core.py:219-385
+  * ``set_triton_mode`` / ``get_triton_mode``                  reference bk_core.py:389-433
+
+The arithmetic runs in hand-written HIP kernels reached through the C ABI of ``libbkcore.so``
+(``include/bkcore.h``).  The numerics are those of the reference's sequential log-scaled path
+(what ``apply(..., False, False)`` computes there); the ``use_triton`` / ``use_parallel_scan``
+arguments and class attributes are accepted and ignored -- there is exactly one back-end.
+Tensors must live on a ROCm device; there is no CPU path.
+"""
+from __future__ import annotations
+
+import logging
+import warnings
+
+import torch
+
+from . import _lib
+
+logger = logging.getLogger(__name__)
+
+_DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16, torch.float64: _lib.F64}
+_state = {}  # (device index, stream handle) -> persistent int32 state block for the NaN-sanitiser corner
+
+
+def _state_block(device: torch.device, stream: int) -> torch.Tensor:
+    key = (device.index, stream)
+    blk = _state.get(key)
+    if blk is None:
+        blk = torch.zeros(_lib.STATE_BYTES // 4, dtype=torch.int32, device=device)
+        _state[key] = blk
+    return blk
+
+
+def _rows(x: torch.Tensor, n_inner: int, name: str):
+    """(tensor kept alive, data_ptr, leading dimension in elements) for a (B, n_inner) operand with unit inner
+    stride.  A broadcast batch dimension (stride 0, as produced by expand()) is passed through as ld = 0."""
+    if x.dim() != 2 or x.shape[1] != n_inner:
+        raise ValueError(f"bkcore: {name} must have shape (B, {n_inner}), got {tuple(x.shape)}")
+    if (n_inner > 1 and x.stride(1) != 1) or x.stride(0) < 0:
+        x = x.contiguous()
+    ld = x.stride(0) if x.shape[0] > 1 else 0
+    return x, x.data_ptr(), ld
+
+
+def _prep_inputs(a, b, c):
+    if a.is_complex() or b.is_complex() or c.is_complex():
+        raise TypeError("bkcore: complex a/b/c are not supported by the HIP kernels (real dtypes only)")
+    if not a.is_cuda:
+        raise RuntimeError("bkcore: tensors must be on a ROCm device (no CPU path; use the oracle for CPU checks)")
+    dt = a.dtype
+    if dt not in _DTYPES:
+        a = a.float()
+        dt = torch.float32
+    if b.dtype != dt:
+        b = b.to(dt)
+    if c.dtype != dt:
+        c = c.to(dt)
+    if b.device != a.device or c.device != a.device:
+        raise RuntimeError("bkcore: a, b, c must be on the same device")
+    return a, b, c, _DTYPES[dt]
+
+
+def _prep_z(z, device):
+    """-> (keepalive tensor or None, device pointer or None, re, im)"""
+    if isinstance(z, (int, float, complex)):
+        zc = complex(z)
+        return None, None, float(zc.real), float(zc.imag)
+    if not torch.is_tensor(z):
+        raise TypeError(f"bkcore: z must be a python scalar or a 0-dim tensor, got {type(z)}")
+    if z.numel() != 1:
+        raise ValueError("bkcore: z must hold exactly one value")
+    if z.is_cuda:
+        zz = z.detach().reshape(())
+        if zz.device != device:
+            zz = zz.to(device)
+        if zz.dtype != torch.complex64:
+            zz = zz.to(torch.complex64)
+        zr = torch.view_as_real(zz.contiguous())
+        return zr, zr.data_ptr(), 0.0, 0.0
+    zc = complex(z.detach().reshape(()).item())
+    return None, None, float(zc.real), float(zc.imag)
+
+
+def bk_forward(a, b, c, z, raw: bool = False, phi_exact: bool = False, want_features: bool = True):
+    """Launch the HIP forward.  a (B,N), b/c (B,N-1) real tensors on the GPU.  Returns (features|None, G)."""
+    L = _lib.load()
+    a, b, c, dt = _prep_inputs(a, b, c)
+    B, N = a.shape
+    nb = max(N - 1, 0)
+    G = torch.empty((B, N), dtype=torch.complex64, device=a.device)
+    feats = torch.empty((B, N, 2), dtype=torch.float32, device=a.device) if want_features else None
+    if B == 0 or N == 0:
+        return feats, G
+    a, pa, lda = _rows(a, N, "a")
+    b, pb, ldb = _rows(b, nb, "b")
+    c, pc, ldc = _rows(c, nb, "c")
+    with torch.cuda.device(a.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        zkeep, pz, zre, zim = _prep_z(z, a.device)
+        state = None if raw else _state_block(a.device, stream)
+        flags = (_lib.FLAG_RAW if raw else 0) | (_lib.FLAG_PHI_EXACT if phi_exact else 0)
+        rc = L.bkcore_forward(pa, lda, pb if nb else None, ldb, pc if nb else None, ldc, dt, pz, zre, zim, B, N,
+                              G.data_ptr(), feats.data_ptr() if feats is not None else None,
+                              state.data_ptr() if state is not None else None, flags, stream)
+    _lib.check(rc, "bkcore_forward")
+    del zkeep
+    return feats, G
+
+
+def bk_backward_reference(G, grad_features, grad_G, alpha: float):
+    """Launch the reference-mode backward kernel.  Returns grad_he_diag float32 with G's shape."""
+    L = _lib.load()
+    G = G.contiguous()
+    out = torch.empty(G.shape, dtype=torch.float32, device=G.device)
+    n = G.numel()
+    if n == 0:
+        return out
+    gf = None
+    if grad_features is not None:
+        gf = grad_features
+        if gf.dtype != torch.float32:
+            gf = gf.float()
+        gf = gf.contiguous()
+    gg = None
+    if grad_G is not None:
+        gg = grad_G
+        if gg.dtype != torch.complex64:
+            gg = gg.to(torch.complex64)
+        gg = gg.contiguous()
+    with torch.cuda.device(G.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = L.bkcore_backward_ref(G.data_ptr(), gf.data_ptr() if gf is not None else None,
+                                   gg.data_ptr() if gg is not None else None, float(alpha), n, out.data_ptr(), stream)
+    _lib.check(rc, "bkcore_backward_ref")
+    return out
+
+
+def vmapped_get_diag(a, b, c, z):
+    """Batched diag((T - zI)^-1): (B,N),(B,N-1),(B,N-1),z -> (B,N) complex64.  No input clamps
+    (reference bk_core.py:214-216)."""
+    return bk_forward(a, b, c, z, raw=True, phi_exact=(BKCoreFunction.PHI_K_INDEX == "exact"),
+                      want_features=False)[1]
+
+
+def get_tridiagonal_inverse_diagonal(a, b, c, z):
+    """One row: a (N,), b (N-1,), c (N-1,) -> (N,) complex64 (reference bk_core.py:27-210)."""
+    return vmapped_get_diag(a.unsqueeze(0), b.unsqueeze(0), c.unsqueeze(0), z)[0]
+
+
+class BKCoreFunction(torch.autograd.Function):
+    """BK-Core autograd operator with the reference's signature (bk_core.py:219-385).
+
+    Class attributes kept from the reference: ``GRAD_BLEND`` (read at backward time, bk_core.py:366),
+    ``USE_TRITON`` and ``USE_PARALLEL_SCAN`` (accepted, select nothing).
+    Added here: ``PHI_K_INDEX`` in {"reference", "exact"} chooses the off-diagonal product used by the
+    phi recurrence (the reference uses k_i, bk_core.py:171).
+    """
+    GRAD_BLEND = 0.5
+    USE_TRITON = None
+    USE_PARALLEL_SCAN = True
+    PHI_K_INDEX = "reference"
+
+    @staticmethod
+    def forward(ctx, he_diag, h0_super, h0_sub, z, use_triton=None, use_parallel_scan=None):
+        lead = he_diag.shape[:-1]
+        n = he_diag.shape[-1]
+        a2 = he_diag.reshape(-1, n) if he_diag.dim() != 2 else he_diag
+        b2 = h0_super.reshape(-1, max(n - 1, 0)) if h0_super.dim() != 2 else h0_super
+        c2 = h0_sub.reshape(-1, max(n - 1, 0)) if h0_sub.dim() != 2 else h0_sub
+        feats, G = bk_forward(a2.detach(), b2.detach(), c2.detach(), z, raw=False,
+                              phi_exact=(BKCoreFunction.PHI_K_INDEX == "exact"))
+        if he_diag.dim() != 2:
+            feats = feats.reshape(*lead, n, 2)
+            G = G.reshape(*lead, n)
+        ctx.save_for_backward(G)                       # only G is saved (bk_core.py:293)
+        return feats, G
+
+    @staticmethod
+    def backward(ctx, grad_output_features, grad_G_ii):
+        (G,) = ctx.saved_tensors
+        grad = bk_backward_reference(G, grad_output_features, grad_G_ii, BKCoreFunction.GRAD_BLEND)
+        return grad, None, None, None, None, None
+
+
+def set_triton_mode(enabled: bool):
+    """Kept for source compatibility (reference bk_core.py:389-416).  There is no Triton back-end here;
+    the flag is recorded and selects nothing."""
+    BKCoreFunction.USE_TRITON = bool(enabled)
+    if enabled:
+        warnings.warn("Triton is not used by this build; BK-Core always runs the HIP kernels.", UserWarning)
+        BKCoreFunction.USE_TRITON = False
+
+
+def get_triton_mode() -> bool:
+    """Always False: no Triton back-end (reference bk_core.py:419-433)."""
+    return False

@@ -1,0 +1,66 @@
+"""CPU-side checks of the C-ABI shared library: it loads and exports every symbol include/bkcore.h declares.
+No compute call is made here (no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "bkcore.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bkcore_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    fns = declared_functions()
+    for must in ("bkcore_forward", "bkcore_backward_ref", "bkcore_max_seq_len", "bkcore_error_string"):
+        assert must in fns
+
+
+def test_library_exports_every_declared_symbol():
+    from bkcore import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build libbkcore.so first (python -c 'import __graft_entry__ as g; g.build()')"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for fn in declared_functions():
+        assert hasattr(L, fn), f"{fn} declared in include/bkcore.h but not exported by libbkcore.so"
+    assert set(_lib.EXPORTS) <= set(declared_functions())
+
+
+def test_host_side_argument_checks():
+    # these return before any HIP call, so they run without a GPU
+    from bkcore import _lib
+    L = _lib.load()
+    assert L.bkcore_abi_version() == _lib.ABI_VERSION
+    assert L.bkcore_max_seq_len() >= 1 << 20
+    assert L.bkcore_forward(None, 0, None, 0, None, 0, 0, None, 0.0, 1.0, 4, 16, None, None, None, 0, None) == -1
+    assert L.bkcore_forward(None, 0, None, 0, None, 0, 0, None, 0.0, 1.0, 0, 16, None, None, None, 0, None) == 0
+    assert L.bkcore_forward(None, 0, None, 0, None, 0, 0, None, 0.0, 1.0, -1, 16, None, None, None, 0, None) == -1
+    assert L.bkcore_backward_ref(None, None, None, 0.5, 0, None, None) == 0
+    assert L.bkcore_backward_ref(None, None, None, 0.5, 8, None, None) == -1
+    assert b"invalid" in L.bkcore_error_string(-1)
+    assert b"sequence length" in L.bkcore_error_string(-2)
+
+
+def test_operator_refuses_cpu_tensors():
+    import torch
+    import bkcore
+    a = torch.zeros(2, 8)
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        bkcore.BKCoreFunction.apply(a, a[:, :-1], a[:, :-1], 1j)
+
+
+def test_reference_api_surface():
+    # names the reference module exports (src/models/bk_core.py) exist with the same call shape
+    import inspect
+    import bkcore
+    from bkcore.bk_core import BKCoreFunction
+    assert BKCoreFunction.GRAD_BLEND == 0.5
+    assert hasattr(BKCoreFunction, "USE_TRITON") and hasattr(BKCoreFunction, "USE_PARALLEL_SCAN")
+    params = list(inspect.signature(BKCoreFunction.forward).parameters)
+    assert params == ["ctx", "he_diag", "h0_super", "h0_sub", "z", "use_triton", "use_parallel_scan"]
+    assert bkcore.get_triton_mode() is False

@@ -1,0 +1,224 @@
+"""GPU parity tests: HIP kernels (through the C ABI / the operator wrapper) against the CPU oracle and
+against the golden fixtures recorded from the reference.
+
+Tolerance (stated by the task's north star): max relative error <= 1e-4 on the complex64 G and on the
+gradients, measured elementwise as |x - ref| / |ref|.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import max_rel_err
+from test_oracle_golden import ALL
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def bk():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import bkcore
+    return bkcore
+
+
+@pytest.fixture(scope="module")
+def coracle():
+    from oracle import bk_oracle_c as C
+    C.lib()
+    return C
+
+
+def _z(cs):
+    return complex(cs["z"][0], cs["z"][1])
+
+
+def _dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def _lap(B, N, seed, varying=False):
+    g = torch.Generator().manual_seed(seed)
+    a = -2.0 + 0.5 * torch.randn(B, N, generator=g)
+    if varying:
+        b = 1.0 + 0.1 * torch.randn(B, N - 1, generator=g)
+        c = 1.0 + 0.1 * torch.randn(B, N - 1, generator=g)
+    else:
+        b = torch.ones(B, N - 1)
+        c = torch.ones(B, N - 1)
+    return a, b, c
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_golden_forward(bk, golden, name):
+    cs = golden[name]
+    a, b, c = _dev(cs["a"]), _dev(cs["b"]), _dev(cs["c"])
+    z = torch.tensor(_z(cs), dtype=torch.complex64, device="cuda")
+    feats, G = bk.BKCoreFunction.apply(a, b, c, z)
+    assert feats.shape == cs["features"].shape and feats.dtype == torch.float32
+    assert G.shape == cs["G"].shape and G.dtype == torch.complex64
+    Gh = G.cpu().numpy()
+    ref = cs["G"]
+    zero = ref == 0
+    assert np.array_equal(Gh == 0, zero)
+    assert max_rel_err(Gh[~zero], ref[~zero]) <= TOL
+    assert np.array_equal(feats.cpu().numpy(), np.stack([Gh.real, Gh.imag], -1))
+
+
+@pytest.mark.parametrize("name", [n for n in ALL if n not in ("poisoned", "nan_offdiag_only", "clamped_inputs")])
+def test_golden_raw_get_diag(bk, golden, name):
+    cs = golden[name]
+    G = bk.vmapped_get_diag(_dev(cs["a"]), _dev(cs["b"]), _dev(cs["c"]), _z(cs)).cpu().numpy()
+    assert max_rel_err(G, cs["G_raw"]) <= TOL
+
+
+@pytest.mark.parametrize("name", ALL)
+@pytest.mark.parametrize("alpha", [0.0, 0.5, 1.0])
+@pytest.mark.parametrize("with_gG", [False, True])
+def test_golden_reference_backward(bk, golden, name, alpha, with_gG):
+    # the backward kernel alone, fed the reference's own saved G: isolates the elementwise formula
+    cs = golden[name]
+    got = bk.bk_backward_reference(_dev(cs["G"]), _dev(cs["gfeat"]), _dev(cs["gG"]) if with_gG else None, alpha)
+    ref = cs[f"grad_ref_a{alpha}_gG{int(with_gG)}"]
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_autograd_function_end_to_end(bk, golden):
+    # forward + backward through torch autograd, as the reference's test does (tests/test_bk_core.py:130-158)
+    cs = golden["lap_n64_b8"]
+    a = _dev(cs["a"]).requires_grad_(True)
+    z = torch.tensor(1j, dtype=torch.complex64, device="cuda")
+    gf = _dev(cs["gfeat"])
+    for alpha in (0.0, 0.5, 1.0):
+        bk.BKCoreFunction.GRAD_BLEND = alpha
+        a.grad = None
+        feats, G = bk.BKCoreFunction.apply(a, _dev(cs["b"]), _dev(cs["c"]), z)
+        (feats * gf).sum().backward()
+        ref = cs[f"grad_ref_a{alpha}_gG0"]
+        got = a.grad.cpu().numpy()
+        # the reference gradient has terms ~1/G^2, so a 1e-5 relative difference in G moves it by ~2e-5
+        assert np.max(np.abs(got - ref) / (np.abs(ref) + 1e-3 * np.abs(ref).max())) <= 2e-4
+    bk.BKCoreFunction.GRAD_BLEND = 0.5
+    assert a.grad.dtype == torch.float32 and a.grad.shape == a.shape
+
+
+@pytest.mark.parametrize("B,N", [(8, 1024), (3, 2047), (3, 2048), (3, 2049), (2, 4097), (5, 300), (4, 8192), (2, 32768)])
+@pytest.mark.parametrize("varying", [False, True])
+def test_seeded_vs_c_oracle(bk, coracle, B, N, varying):
+    a, b, c = _lap(B, N, 77 + N + B, varying)
+    z = 1j
+    Gref = coracle.get_diag(a.numpy(), b.numpy(), c.numpy(), z)
+    G = bk.vmapped_get_diag(a.cuda(), b.cuda(), c.cuda(), z).cpu().numpy()
+    assert max_rel_err(G, Gref) <= TOL
+    if varying:
+        bk.BKCoreFunction.PHI_K_INDEX = "exact"
+        try:
+            Ge = bk.vmapped_get_diag(a.cuda(), b.cuda(), c.cuda(), z).cpu().numpy()
+        finally:
+            bk.BKCoreFunction.PHI_K_INDEX = "reference"
+        Geref = coracle.get_diag(a.numpy(), b.numpy(), c.numpy(), z, phi_exact=True)
+        assert max_rel_err(Ge, Geref) <= TOL
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 7, 8, 9, 63, 64, 65, 255, 256, 257, 511, 513])
+def test_small_and_ragged_lengths(bk, coracle, N):
+    g = torch.Generator().manual_seed(N)
+    B = 3
+    a = -2.0 + 0.5 * torch.randn(B, N, generator=g)
+    b = 1.0 + 0.1 * torch.randn(B, max(N - 1, 0), generator=g)
+    c = 1.0 + 0.1 * torch.randn(B, max(N - 1, 0), generator=g)
+    z = 0.3 + 0.9j
+    feats, G = bk.BKCoreFunction.apply(a.cuda(), b.cuda(), c.cuda(), z)
+    F, Gref = coracle.forward_f32(a.numpy(), b.numpy(), c.numpy(), z)
+    assert max_rel_err(G.cpu().numpy(), Gref) <= TOL
+
+
+def test_empty_inputs(bk):
+    z = 1j
+    feats, G = bk.BKCoreFunction.apply(torch.zeros(4, 0, device="cuda"), torch.zeros(4, 0, device="cuda"),
+                                       torch.zeros(4, 0, device="cuda"), z)
+    assert G.shape == (4, 0) and feats.shape == (4, 0, 2)
+    feats, G = bk.BKCoreFunction.apply(torch.zeros(0, 16, device="cuda"), torch.zeros(0, 15, device="cuda"),
+                                       torch.zeros(0, 15, device="cuda"), z)
+    assert G.shape == (0, 16) and feats.shape == (0, 16, 2)
+
+
+def test_broadcast_rows_and_dtypes(bk, coracle):
+    # the layer passes expand()ed (stride-0) off-diagonals and bf16 inputs (resnet_bk.py:155-170)
+    B, N = 6, 700
+    g = torch.Generator().manual_seed(5)
+    a = (1.0 + 5.0 * torch.tanh(torch.randn(B, N, generator=g) / 5.0))
+    b1 = 0.5 + 0.1 * torch.randn(1, N - 1, generator=g)
+    c1 = 0.7 + 0.1 * torch.randn(1, N - 1, generator=g)
+    z = torch.tensor(1.3133j, dtype=torch.complex64)
+    for dt in (torch.bfloat16, torch.float16, torch.float32, torch.float64):
+        ad, bd, cd = a.to(dt), b1.to(dt), c1.to(dt)
+        _, Gref = coracle.forward_f32(ad.float().numpy(), bd.float().expand(B, -1).numpy(),
+                                      cd.float().expand(B, -1).numpy(), complex(z))
+        feats, G = bk.BKCoreFunction.apply(ad.cuda(), bd.cuda().expand(B, -1), cd.cuda().expand(B, -1), z.cuda())
+        assert max_rel_err(G.cpu().numpy(), Gref) <= TOL, dt
+
+
+def test_z_forms_agree(bk):
+    a, b, c = _lap(4, 500, 3)
+    a, b, c = a.cuda(), b.cuda(), c.cuda()
+    z = 0.25 + 0.8j
+    G0 = bk.vmapped_get_diag(a, b, c, z)
+    G1 = bk.vmapped_get_diag(a, b, c, torch.tensor(z, dtype=torch.complex64))
+    G2 = bk.vmapped_get_diag(a, b, c, torch.tensor(z, dtype=torch.complex64, device="cuda"))
+    G3 = bk.vmapped_get_diag(a, b, c, torch.tensor(z, dtype=torch.complex128, device="cuda"))
+    assert torch.equal(G0, G1) and torch.equal(G0, G2) and torch.equal(G0, G3)
+    row = bk.get_tridiagonal_inverse_diagonal(a[1], b[1], c[1], z)
+    assert torch.equal(row, G0[1])
+
+
+def test_headline_size_properties(bk, coracle):
+    """B=1024, N=32768 (the headline configuration): parity on a seeded row subset against the oracle,
+    row independence, features == G, bitwise determinism."""
+    B, N = 1024, 32768
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    a = -2.0 + 0.5 * torch.randn(B, N, generator=g, device="cuda")
+    b = torch.ones(B, N - 1, device="cuda")
+    c = torch.ones(B, N - 1, device="cuda")
+    z = torch.tensor(1j, dtype=torch.complex64, device="cuda")
+    feats, G = bk.BKCoreFunction.apply(a, b, c, z)
+    feats2, G2 = bk.BKCoreFunction.apply(a, b, c, z)
+    assert torch.equal(G, G2) and torch.equal(feats, feats2)
+    assert torch.equal(torch.view_as_real(G), feats)
+    assert torch.isfinite(feats).all()
+    rows = [0, 1, 511, 777, 1023]
+    Gref = coracle.get_diag(a[rows].cpu().numpy(), np.ones((len(rows), N - 1)), np.ones((len(rows), N - 1)), 1j)
+    assert max_rel_err(G[rows].cpu().numpy(), Gref) <= TOL
+    # a row computed alone equals the same row computed inside the batch (rows are independent systems)
+    _, Gone = bk.BKCoreFunction.apply(a[777:778], b[777:778], c[777:778], z)
+    assert torch.equal(Gone[0], G[777])
+    # backward at the headline size: elementwise formula against the oracle's on the same rows
+    gf = torch.randn(B, N, 2, generator=g, device="cuda")
+    grad = bk.bk_backward_reference(G, gf, None, 0.5)
+    ref = coracle.backward_ref(G[rows].cpu().numpy(), gf[rows].cpu().numpy(), None, 0.5)
+    np.testing.assert_allclose(grad[rows].cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_long_sequence(bk, coracle):
+    """N = 2^20 (long-context configuration, B reduced to keep the oracle to seconds)."""
+    B, N = 2, 1 << 20
+    a, b, c = _lap(B, N, 99)
+    Gref = coracle.get_diag(a.numpy(), b.numpy(), c.numpy(), 1j)
+    G = bk.vmapped_get_diag(a.cuda(), b.cuda(), c.cuda(), 1j).cpu().numpy()
+    assert max_rel_err(G, Gref) <= TOL
+
+
+def test_too_long_is_rejected(bk):
+    from bkcore import _lib
+    nmax = int(_lib.load().bkcore_max_seq_len())
+    a = torch.zeros(1, nmax + 1, device="cuda")
+    with pytest.raises(RuntimeError, match="sequence length"):
+        bk.vmapped_get_diag(a, a[:, :-1], a[:, :-1], 1j)
+
+
+def test_cpu_tensors_fail_loudly(bk):
+    a = torch.zeros(1, 8)
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        bk.vmapped_get_diag(a, a[:, :-1], a[:, :-1], 1j)
