@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""BK-Core benchmark: forward + backward diag-elements/s on MI355X, with HBM roofline and a CPU baseline.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one BK-Core forward (G and features) plus one reference-mode backward (grad_he_diag) over a
+batch of B = 1024 rows of N = 32768 (BASELINE.json configs[1]) held in HBM.  With N > 1 GPUs (launched by
+torch.distributed.run, one rank per GPU) every rank processes its own B rows -- the operator shards by
+batch row and needs no collective -- and the reported value is the whole-job rate (weak scaling).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the forward scan) by its algorithmic
+bytes (28 B per diag-element: read a, b, c; write G and features) over its average launch time measured
+with stream events; `cpu_baseline` times the CPU oracle (C port of the reference algorithm, OpenMP) on a
+bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "project-resnet-bk-an-o-n-language-model-architecture_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+FWD_BYTES = 28.0   # per diag-element: a,b,c reads (3x4) + G write (8) + features write (8)
+BWD_BYTES = 20.0   # per diag-element: G read (8) + grad_features read (8) + grad_he_diag write (4)
+HBM_PEAK = 8.0e12  # MI355X HBM3E nominal bytes/s
+
+
+def make_inputs(B, N, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    a = (-2.0 + 0.5 * torch.randn(B, N, generator=g, device=device)).requires_grad_(True)
+    b = torch.ones(B, N - 1, device=device)
+    c = torch.ones(B, N - 1, device=device)
+    gfeat = torch.randn(B, N, 2, generator=g, device=device)
+    z = torch.tensor(1j, dtype=torch.complex64, device=device)
+    return a, b, c, z, gfeat
+
+
+def cpu_baseline(N, budget_s=12.0):
+    """C port of the reference algorithm (oracle/bk_oracle.c), fwd + reference bwd, all host threads OpenMP gives."""
+    import numpy as np
+    from oracle import bk_oracle_c as C
+    threads = C.num_threads()
+    rng = np.random.default_rng(0)
+
+    def run(rows):
+        a = (-2.0 + 0.5 * rng.standard_normal((rows, N))).astype(np.float32)
+        b = np.ones((rows, N - 1), np.float32)
+        gf = rng.standard_normal((rows, N, 2)).astype(np.float32)
+        t0 = time.perf_counter()
+        _, G = C.forward_f32(a, b, b, 1j)
+        C.backward_ref(G, gf, None, 0.5)
+        return time.perf_counter() - t0
+
+    rows = 16 * threads
+    run(threads)                          # warm-up: page in, spin up the OpenMP team
+    total_t, total_rows = 0.0, 0
+    while total_t < budget_s:
+        total_t += run(rows)
+        total_rows += rows
+    return {"value": total_rows * N / total_t, "unit": "diag-elems/s", "cores": threads, "kind": "port",
+            "sample": f"C/OpenMP oracle, fwd+bwd, {total_rows} rows x N={N} in {total_t:.2f} s"}
+
+
+def cpu_baseline_torch_loop(N_sub=16384, B=64):
+    """Restatement of the reference's own cost model (Python loop over N of batched complex128 torch ops),
+    forward only, on an N-subsample; the reference path costs ~constant time per sequence position."""
+    from oracle import bk_oracle_torch as O
+    g = torch.Generator().manual_seed(0)
+    a = -2.0 + 0.5 * torch.randn(B, N_sub, generator=g)
+    b = torch.ones(B, N_sub - 1)
+    t0 = time.perf_counter()
+    O.forward(a, b, b, 1j)
+    t = time.perf_counter() - t0
+    return {"value": B * N_sub / t, "unit": "diag-elems/s (fwd only)", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"torch complex128 loop (reference cost model), fwd, B={B} x N={N_sub} in {t:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="rows per GPU")
+    ap.add_argument("--seq", type=int, default=32768)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+
+    import bkcore
+    from bkcore import BKCoreFunction
+    B, N = args.batch, args.seq
+    a, b, c, z, gfeat = make_inputs(B, N, device, 1234 + rank)
+
+    def step():
+        a.grad = None
+        feats, G = BKCoreFunction.apply(a, b, c, z)
+        torch.autograd.backward((feats,), (gfeat,))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # per-kernel launch durations with stream events (same stream the kernels are launched on)
+    def timed(fn, reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    reps = max(5, args.steps)
+    ad = a.detach()
+    with torch.no_grad():
+        G = bkcore.bk_forward(ad, b, c, z)[1]
+        t_fwd = timed(lambda: bkcore.bk_forward(ad, b, c, z), reps)
+        t_bwd = timed(lambda: bkcore.bk_backward_reference(G, gfeat, None, 0.5), reps)
+
+    if rank == 0:
+        elems = B * N
+        ms = dt / args.steps * 1e3
+        value = world * elems / (dt / args.steps)
+        fwd_bw = FWD_BYTES * elems / t_fwd
+        out = {
+            "metric": "bk_core_fwd_bwd_diag_elems_per_sec",
+            "value": value,
+            "unit": "diag-elems/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BK-Core fwd+bwd B={B} N={N} complex64 per GPU (BASELINE.json configs[1]); "
+                                   "he_diag=-2+0.5*randn, h0_super=h0_sub=1, z=1j; reference-mode backward",
+                       "rows_per_gpu": B, "seq_len": N, "sharding": f"batch rows x{world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": fwd_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": fwd_bw / HBM_PEAK, "traffic": None,
+                         "kernel": "bk_forward_kernel", "bytes_per_elem": FWD_BYTES, "launch_ms": t_fwd * 1e3},
+            "fwd_ms": t_fwd * 1e3,
+            "bwd_ms": t_bwd * 1e3,
+            "bwd_GBps": BWD_BYTES * elems / t_bwd / 1e9,
+            "hbm_frac_fwd_bwd": (FWD_BYTES + BWD_BYTES) * elems / (t_fwd + t_bwd) / HBM_PEAK,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N)
+            out["cpu_baseline_reference_cost_model"] = cpu_baseline_torch_loop()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -180,11 +180,14 @@ class BKCoreFunction(torch.autograd.Function):
             feats = feats.reshape(*lead, n, 2)
             G = G.reshape(*lead, n)
         ctx.save_for_backward(G)                       # only G is saved (bk_core.py:293)
+        ctx.set_materialize_grads(False)               # an unused output arrives as None, not as a zero tensor
         return feats, G
 
     @staticmethod
     def backward(ctx, grad_output_features, grad_G_ii):
         (G,) = ctx.saved_tensors
+        if grad_output_features is None and grad_G_ii is None:
+            return None, None, None, None, None, None
         grad = bk_backward_reference(G, grad_output_features, grad_G_ii, BKCoreFunction.GRAD_BLEND)
         return grad, None, None, None, None, None
 
