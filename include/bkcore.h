@@ -41,6 +41,7 @@ extern "C" {
 #define BKCORE_EINVAL (-1)   /* bad argument (null pointer, negative size, unknown dtype) */
 #define BKCORE_ETOOLONG (-2) /* N larger than bkcore_max_seq_len() */
 #define BKCORE_ELAUNCH (-3)  /* HIP launch failed; bkcore_last_hip_error() has the HIP code */
+#define BKCORE_EWORKSPACE (-4) /* workspace missing or smaller than bkcore_workspace_bytes(B, N) */
 
 /* Size in bytes of the persistent per-(device,stream) state block bkcore_forward may be given.
  * Allocate once with device memory, zero it once, reuse it for every call on that stream. */
@@ -67,10 +68,17 @@ extern "C" {
  *    by 1 only when he_diag holds a NaN somewhere in the batch (src/models/bk_core.py:260-264).  With
  *    state == NULL NaNs in b/c are never replaced (such rows then come out as zeros, as in the reference
  *    when he_diag is clean).
+ * workspace: device scratch of at least bkcore_workspace_bytes(B, N) bytes (16-byte aligned), owned by the caller
+ *    and free to reuse as soon as the stream has passed this call; may be NULL when that size is 0.
  */
 int bkcore_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc, int in_dtype,
                    const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
-                   void *state, unsigned flags, void *stream);
+                   void *workspace, size_t workspace_bytes, void *state, unsigned flags, void *stream);
+
+/* Scratch bytes bkcore_forward needs for a (B, N) problem: 0 for N <= 32768 (per-lane scan states stay in LDS),
+ * otherwise 20 bytes per 16 elements (rounded up to whole 4096-element chunks).  No counterpart in the reference,
+ * which allocates its theta/phi buffers inside the call (src/kernels/bk_scan.py:416-417). */
+size_t bkcore_workspace_bytes(int64_t B, int64_t N);
 
 /*
  * Backward, reference mode: grad_he_diag = (1-alpha) * -Re(conj(g) G^2) + alpha * -Re(conj(g)/G^2) with the

@@ -13,9 +13,9 @@ F32, BF16, F16, F64 = 0, 1, 2, 3
 FLAG_RAW = 1
 FLAG_PHI_EXACT = 2
 STATE_BYTES = 64
-ABI_VERSION = 1
+ABI_VERSION = 2
 
-EXPORTS = ("bkcore_forward", "bkcore_backward_ref", "bkcore_max_seq_len", "bkcore_last_hip_error",
+EXPORTS = ("bkcore_forward", "bkcore_workspace_bytes", "bkcore_backward_ref", "bkcore_max_seq_len", "bkcore_last_hip_error",
            "bkcore_error_string", "bkcore_abi_version")
 
 _lib = None
@@ -31,8 +31,10 @@ def load():
             "there is no CPU fallback for this operator.")
     L = ctypes.CDLL(LIB_PATH)
     vp, i64, i32, f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
-    L.bkcore_forward.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp, f32, f32, i64, i64, vp, vp, vp,
-                                 ctypes.c_uint, vp]
+    L.bkcore_forward.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp, f32, f32, i64, i64, vp, vp, vp, ctypes.c_size_t,
+                                 vp, ctypes.c_uint, vp]
+    L.bkcore_workspace_bytes.argtypes = [i64, i64]
+    L.bkcore_workspace_bytes.restype = ctypes.c_size_t
     L.bkcore_forward.restype = i32
     L.bkcore_backward_ref.argtypes = [vp, vp, vp, f32, i64, vp, vp]
     L.bkcore_backward_ref.restype = i32

@@ -106,8 +106,11 @@ def bk_forward(a, b, c, z, raw: bool = False, phi_exact: bool = False, want_feat
         zkeep, pz, zre, zim = _prep_z(z, a.device)
         state = None if raw else _state_block(a.device, stream)
         flags = (_lib.FLAG_RAW if raw else 0) | (_lib.FLAG_PHI_EXACT if phi_exact else 0)
+        ws_bytes = int(L.bkcore_workspace_bytes(B, N))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
         rc = L.bkcore_forward(pa, lda, pb if nb else None, ldb, pc if nb else None, ldc, dt, pz, zre, zim, B, N,
                               G.data_ptr(), feats.data_ptr() if feats is not None else None,
+                              ws.data_ptr() if ws is not None else None, ws_bytes,
                               state.data_ptr() if state is not None else None, flags, stream)
     _lib.check(rc, "bkcore_forward")
     del zkeep

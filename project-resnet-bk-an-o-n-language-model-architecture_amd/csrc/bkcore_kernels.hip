@@ -13,13 +13,19 @@
 //
 // The soft clamp inside the recurrence (bk_core.py:127-136) multiplies kappa_p by
 // w_p = exp(88 tanh(d/88) - d), d = ln|prev2| - ln|prev|, which makes the recurrence weakly
-// non-linear.  It is reproduced by a two-pass fixed point: pass 1 scans the linear recurrence and
-// yields d_p (only the ratio of consecutive terms matters), pass 2 scans with kappa_p * w_p.
+// non-linear.  Lane aggregates need w_p before the lane's incoming state is known, so they are
+// built by a two-pass fixed point: pass 1 scans the linear recurrence and yields d_p (only the
+// ratio of consecutive terms matters), pass 2 scans with kappa_p * w_p.  Once a lane's incoming
+// state is known the lane can also run the non-linear recurrence itself, exactly as the reference
+// does step by step.
 //
-// Kernel shape (one workgroup of 256 threads per row, chunks of 256 x E elements):
-//   sweep A, chunks left -> right : theta scan, keeps only the chunk-boundary carries (LDS)
-//   sweep B, chunks right -> left : phi scan with a running carry, theta re-scanned inside the
-//                                   chunk from the saved carry, epilogue, stores of G / features.
+// Kernel shape: one workgroup of 256 threads per row, chunks of 256 x 16 elements, each thread
+// owning 16 consecutive elements of a chunk in registers.
+//   sweep A, chunks left -> right : theta two-pass scan; stores each lane's incoming theta state
+//                                   (20 bytes per 16 elements) to LDS or to a workspace
+//   sweep B, chunks right -> left : theta re-run inside the lane from the stored state, phi two-pass
+//                                   scan with a running carry, epilogue fused into the last phi
+//                                   re-run, G / features staged through LDS for coalesced stores.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -28,12 +34,14 @@
 namespace {
 
 constexpr int T = 256;             // threads per workgroup
-constexpr int E = 8;               // elements per thread per chunk
+constexpr int E = 16;              // elements per thread per chunk
 constexpr int CHUNK = T * E;       // elements per chunk
 constexpr int WAVES = T / 64;
-constexpr int MAX_CHUNKS = 512;    // chunk-boundary carries kept in LDS
+constexpr int LDS_STATE_CHUNKS = 8;  // rows of up to this many chunks keep the lane states in LDS
+constexpr long MAX_N = 1L << 24;
 constexpr float LN2_HALF = 0.34657359027997264f;  // 0.5 * ln 2
 constexpr float LOG2E = 1.4426950408889634f;
+constexpr float WALL_DMAX = 22.0f;                // |d| beyond this is clamped in the series below
 
 struct Vec {  // (x0, x1) * 2^e : two consecutive terms of a recurrence
   float2 x0, x1;
@@ -59,6 +67,7 @@ __device__ __forceinline__ float amax2(float2 p) { return fmaxf(fabsf(p.x), fabs
 __device__ __forceinline__ float2 ld2(float2 p, int e) { return make_float2(ldexpf(p.x, e), ldexpf(p.y, e)); }
 // exponent e with m * 2^-e in [0.5,1); 0 for m == 0, inf, nan
 __device__ __forceinline__ int expo(float m) { return __builtin_amdgcn_frexp_expf(m); }
+__device__ __forceinline__ float log2_norm2(float2 p) { return __builtin_amdgcn_logf(fmaf(p.x, p.x, p.y * p.y)); }
 
 __device__ __forceinline__ void vnorm(Vec &v) {
   const int de = expo(fmaxf(amax2(v.x0), amax2(v.x1)));
@@ -124,39 +133,74 @@ __device__ __forceinline__ Mat mat_shfl(const Mat &m, int src) {
 }
 
 // exp(88 tanh(d/88) - d): the reference's soft clamp exp(88 tanh(d/88)) (bk_core.py:60-75) relative to exp(d).
-// |d| <= 8: tanh series (next term < 1e-9); otherwise evaluated directly.  Non-finite d (a zero term) gives 1.
-__device__ __forceinline__ float wall_corr(float d) {
-  const float u = d * (1.0f / 88.0f);
+// Branch-free: tanh series to u^11 (relative error of the exponent < 2e-6 for |d| <= 22); |d| is clamped to 22
+// (a ratio of consecutive terms beyond e^22 is below float32 resolution of the recurrence).  A non-finite d
+// (an exactly zero term, e.g. the start vector's theta_{-1} = 0) gives 1.
+__device__ __forceinline__ float wall_exponent(float d) {
+  const float dc = fminf(fmaxf(d, -WALL_DMAX), WALL_DMAX);
+  const float u = dc * (1.0f / 88.0f);
   const float s = u * u;
-  float g = -88.0f * u * s * fmaf(-s, fmaf(-s, 17.0f / 315.0f, 2.0f / 15.0f), 1.0f / 3.0f);
-  if (__builtin_expect(fabsf(d) > 8.0f, 0)) g = fmaf(88.0f, tanhf(u), -d);
-  float w = __builtin_amdgcn_exp2f(g * LOG2E);
+  float p = fmaf(s, 1382.0f / 155925.0f, -62.0f / 2835.0f);
+  p = fmaf(s, p, 17.0f / 315.0f);
+  p = fmaf(s, p, -2.0f / 15.0f);
+  p = fmaf(s, p, 1.0f / 3.0f);
+  return -88.0f * u * s * p;
+}
+__device__ __forceinline__ float wall_corr(float d) {
+  float w = __builtin_amdgcn_exp2f(wall_exponent(d) * LOG2E);
   if (!(fabsf(d) <= 3.0e38f)) w = 1.0f;
   return w;
 }
 
+constexpr int A_PAD = CHUNK + CHUNK / 32 + 8;
+constexpr int O_PAD = CHUNK + CHUNK / 16 + 8;
+
 struct Shared {
-  float a_s[CHUNK + CHUNK / 32 + 8];      // staged diagonal (padded: idx + idx/32)
-  float k_s[CHUNK + 1 + CHUNK / 32 + 8];  // staged k_{i-1} = b_{i-1} c_{i-1} for i = chunk_base .. chunk_base+CHUNK
-  Mat tot[2][WAVES];                      // per-wave aggregates, double-buffered across scans
-  Vec carry1[MAX_CHUNKS];                 // theta carries entering each chunk, pass 1 (linear)
-  Vec carry2[MAX_CHUNKS];                 // theta carries entering each chunk, pass 2 (wall-corrected)
+  union {
+    struct {
+      float a_s[A_PAD];       // staged diagonal, index idx + idx/32
+      float k_s[A_PAD + 4];   // staged k_{i-1} = b_{i-1} c_{i-1} for i = chunk_base .. chunk_base+CHUNK (CHUNK+1 values)
+    } in;
+    float2 out_s[O_PAD];      // G of one chunk, index idx + idx/16, for coalesced stores
+  } u;
+  Mat tot[2][WAVES];          // per-wave aggregates, double-buffered across scans
 };
 
-__device__ __forceinline__ int pad(int idx) { return idx + (idx >> 5); }
+__device__ __forceinline__ int pad32(int idx) { return idx + (idx >> 5); }
+__device__ __forceinline__ int pad16(int idx) { return idx + (idx >> 4); }
 
 // ---- lane-level serial pieces -------------------------------------------------------------------------------
+// Element order inside a lane: ascending for theta, descending (REV) for phi.  kw holds k_{i-1} for the lane's
+// elements plus one more (k of the lane's last element); KO selects which one a step uses.
 
-// Product of the lane's E transfer matrices in processing order (REV: element E-1 first).
-template <bool REV, bool TAIL>
-__device__ __forceinline__ Mat lane_aggregate(const float2 (&al)[E], const float (&ka)[E], unsigned vmask) {
+// Product of the lane's E transfer matrices in processing order.
+template <bool REV, bool TAIL, int KO>
+__device__ __forceinline__ Mat lane_aggregate(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask) {
   Mat A = mat_identity();
 #pragma unroll
   for (int j = 0; j < E; ++j) {
     const int ei = REV ? E - 1 - j : j;
     if (!TAIL || ((vmask >> ei) & 1u)) {
-      const float2 na = rstep(al[ei], ka[ei], A.a, A.c);
-      const float2 nb = rstep(al[ei], ka[ei], A.b, A.d);
+      const float2 na = rstep(al[ei], kw[ei + KO], A.a, A.c);
+      const float2 nb = rstep(al[ei], kw[ei + KO], A.b, A.d);
+      A.c = A.a;
+      A.d = A.b;
+      A.a = na;
+      A.b = nb;
+    }
+    if ((j & 1) == 1) mnorm(A);
+  }
+  return A;
+}
+template <bool REV, bool TAIL>
+__device__ __forceinline__ Mat lane_aggregate2(const float2 (&al)[E], const float (&k2)[E], unsigned vmask) {
+  Mat A = mat_identity();
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const int ei = REV ? E - 1 - j : j;
+    if (!TAIL || ((vmask >> ei) & 1u)) {
+      const float2 na = rstep(al[ei], k2[ei], A.a, A.c);
+      const float2 nb = rstep(al[ei], k2[ei], A.b, A.d);
       A.c = A.a;
       A.d = A.b;
       A.a = na;
@@ -167,19 +211,19 @@ __device__ __forceinline__ Mat lane_aggregate(const float2 (&al)[E], const float
   return A;
 }
 
-// Pass 1 re-run from the lane's incoming state: wall factor per element -> k2 = ka * w.
-template <bool REV, bool TAIL>
-__device__ __forceinline__ void rerun_wall(const float2 (&al)[E], const float (&ka)[E], unsigned vmask, Vec x,
+// Pass-1 re-run from the lane's incoming state: wall factor per element -> k2 = k * w.
+template <bool REV, bool TAIL, int KO>
+__device__ __forceinline__ void rerun_wall(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask, Vec x,
                                            float (&k2)[E]) {
-  float l0 = __builtin_amdgcn_logf(fmaf(x.x0.x, x.x0.x, x.x0.y * x.x0.y));  // log2 |x0|^2
-  float l1 = __builtin_amdgcn_logf(fmaf(x.x1.x, x.x1.x, x.x1.y * x.x1.y));
+  float l0 = log2_norm2(x.x0);
+  float l1 = log2_norm2(x.x1);
 #pragma unroll
   for (int j = 0; j < E; ++j) {
     const int ei = REV ? E - 1 - j : j;
     const float d = LN2_HALF * (l1 - l0);  // ln|prev2| - ln|prev|
-    k2[ei] = ka[ei] * wall_corr(d);
+    k2[ei] = kw[ei + KO] * wall_corr(d);
     if (!TAIL || ((vmask >> ei) & 1u)) {
-      const float2 y = rstep(al[ei], ka[ei], x.x0, x.x1);
+      const float2 y = rstep(al[ei], kw[ei + KO], x.x0, x.x1);
       x.x1 = x.x0;
       x.x0 = y;
       l1 = l0;
@@ -189,25 +233,37 @@ __device__ __forceinline__ void rerun_wall(const float2 (&al)[E], const float (&
         x.x1 = ld2(x.x1, -de);
         l1 -= 2.0f * (float)de;
       }
-      l0 = __builtin_amdgcn_logf(fmaf(x.x0.x, x.x0.x, x.x0.y * x.x0.y));
+      l0 = log2_norm2(x.x0);
     }
   }
 }
 
-// Pass 2 re-run: incoming first component (mantissa, exponent) per element.
-template <bool REV, bool TAIL>
-__device__ __forceinline__ void rerun_out(const float2 (&al)[E], const float (&k2)[E], unsigned vmask, Vec x,
-                                          float2 (&om)[E], int (&oe)[E]) {
+// theta inside one lane from its exact incoming state: the non-linear recurrence itself (wall factor from the
+// running state, as bk_core.py:116-140 does).  Outputs theta_i mantissas; exponents are shared by element pairs.
+template <bool TAIL>
+__device__ __forceinline__ void theta_lane(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask, Vec x,
+                                           float2 (&om)[E], int (&oe)[E / 2]) {
+  float l0 = log2_norm2(x.x0);
+  float l1 = log2_norm2(x.x1);
 #pragma unroll
   for (int j = 0; j < E; ++j) {
-    const int ei = REV ? E - 1 - j : j;
-    om[ei] = x.x0;
-    oe[ei] = x.e;
-    if (!TAIL || ((vmask >> ei) & 1u)) {
-      const float2 y = rstep(al[ei], k2[ei], x.x0, x.x1);
+    om[j] = x.x0;
+    if ((j & 1) == 0) oe[j >> 1] = x.e;
+    const float d = LN2_HALF * (l1 - l0);
+    const float kk = kw[j] * wall_corr(d);
+    if (!TAIL || ((vmask >> j) & 1u)) {
+      const float2 y = rstep(al[j], kk, x.x0, x.x1);
       x.x1 = x.x0;
       x.x0 = y;
-      if ((j & 1) == 1) vnorm(x);
+      l1 = l0;
+      if ((j & 1) == 1) {
+        const int de = expo(fmaxf(amax2(x.x0), amax2(x.x1)));
+        x.x0 = ld2(x.x0, -de);
+        x.x1 = ld2(x.x1, -de);
+        x.e += de;
+        l1 -= 2.0f * (float)de;
+      }
+      l0 = log2_norm2(x.x0);
     }
   }
 }
@@ -247,19 +303,6 @@ __device__ __forceinline__ Vec block_exclusive(Mat A, Vec &carry, Shared &sh, in
   return matvec(ex, xin);
 }
 
-// Two-pass scan of one chunk in one direction.
-template <bool REV, bool TAIL, bool WANT_OUT>
-__device__ __forceinline__ void scan_dir(const float2 (&al)[E], const float (&ka)[E], unsigned vmask, Vec &c1, Vec &c2,
-                                         float2 (&om)[E], int (&oe)[E], Shared &sh, int &scan_count) {
-  Mat A = lane_aggregate<REV, TAIL>(al, ka, vmask);
-  Vec x = block_exclusive<REV>(A, c1, sh, scan_count);
-  float k2[E];
-  rerun_wall<REV, TAIL>(al, ka, vmask, x, k2);
-  A = lane_aggregate<REV, TAIL>(al, k2, vmask);
-  x = block_exclusive<REV>(A, c2, sh, scan_count);
-  if (WANT_OUT) rerun_out<REV, TAIL>(al, k2, vmask, x, om, oe);
-}
-
 // ---- input staging ------------------------------------------------------------------------------------------
 template <typename TIn>
 __device__ __forceinline__ float to_f32(TIn v);
@@ -277,95 +320,166 @@ __device__ __forceinline__ float clamp_keep_nan(float v, float lim) { return v <
 struct RowCfg {
   float2 z;
   long N;
-  bool raw;        // no clamp / sanitise
-  bool phi_exact;
-  bool fix_bc;     // replace NaN in b/c by 1 (second launch when he_diag held a NaN)
+  bool raw;     // no clamp / sanitise
+  bool fix_bc;  // replace NaN in b/c by 1 (second launch when he_diag held a NaN)
 };
 
-// Stages chunk `ch` of one row into LDS: a_s[idx] = a[base+idx], k_s[idx] = b[g] c[g] with g = base-1+idx.
+// Stages chunk at `base` of one row into LDS: a_s[idx] = a[base+idx], k_s[idx] = b[g] c[g] with g = base-1+idx.
 // Returns bit0: NaN seen in a, bit1: NaN seen in b or c.
 template <typename TIn>
 __device__ __forceinline__ unsigned stage_chunk(const TIn *__restrict__ a, const TIn *__restrict__ b,
                                                 const TIn *__restrict__ c, long base, const RowCfg &cfg, Shared &sh) {
   unsigned seen = 0;
   const int t = threadIdx.x;
+  float av[E], bv[E + 1], cv[E + 1];
+  // issue all global loads first, then convert / sanitise / write to LDS
 #pragma unroll
   for (int j = 0; j < E; ++j) {
-    const int idx = t + j * T;
-    const long gi = base + idx;
-    float v = 1.0f;
-    if (gi < cfg.N) {
-      v = to_f32<TIn>(a[gi]);
-      if (!cfg.raw) {
-        v = clamp_keep_nan(v, 100.0f);
-        if (v != v) { v = 0.0f; seen |= 1u; }
-      }
-    }
-    sh.a_s[pad(idx)] = v;
+    const long gi = base + t + j * T;
+    av[j] = (gi < cfg.N) ? to_f32<TIn>(a[gi]) : 1.0f;
   }
 #pragma unroll
   for (int j = 0; j <= E; ++j) {
-    const int idx = t + j * T;
+    const long g = base - 1 + t + j * T;
+    const bool ok = (j < E || t == 0) && g >= 0 && g < cfg.N - 1;
+    bv[j] = ok ? to_f32<TIn>(b[g]) : 0.0f;
+    cv[j] = ok ? to_f32<TIn>(c[g]) : 0.0f;
+  }
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    float v = av[j];
+    if (!cfg.raw) {
+      v = clamp_keep_nan(v, 100.0f);
+      if (v != v) { v = 0.0f; seen |= 1u; }
+    }
+    sh.u.in.a_s[pad32(t + j * T)] = v;
+  }
+#pragma unroll
+  for (int j = 0; j <= E; ++j) {
     if (j < E || t == 0) {
-      const long g = base - 1 + idx;
-      float k = 0.0f;
-      if (g >= 0 && g < cfg.N - 1) {
-        float bv = to_f32<TIn>(b[g]);
-        float cv = to_f32<TIn>(c[g]);
-        if (!cfg.raw) {
-          bv = clamp_keep_nan(bv, 10.0f);
-          cv = clamp_keep_nan(cv, 10.0f);
-          if (bv != bv) { seen |= 2u; if (cfg.fix_bc) bv = 1.0f; }
-          if (cv != cv) { seen |= 2u; if (cfg.fix_bc) cv = 1.0f; }
-        }
-        k = bv * cv;
+      float p = bv[j], q = cv[j];
+      if (!cfg.raw) {
+        p = clamp_keep_nan(p, 10.0f);
+        q = clamp_keep_nan(q, 10.0f);
+        if (p != p) { seen |= 2u; if (cfg.fix_bc) p = 1.0f; }
+        if (q != q) { seen |= 2u; if (cfg.fix_bc) q = 1.0f; }
       }
-      sh.k_s[pad(idx)] = k;
+      sh.u.in.k_s[pad32(t + j * T)] = p * q;
     }
   }
   return seen;
 }
 
-// Reads the thread's E elements back in blocked order and forms alpha = reg(a - z) (bk_core.py:78-94),
-// kth[e] = k_{i-1} (theta, and phi under the reference convention), kph[e] (phi).
+// Reads the thread's E elements back in blocked order and forms alpha = reg(a - z) (bk_core.py:78-94) and
+// kw[e] = k_{i-1} for i = first element + e, e = 0..E.
 __device__ __forceinline__ void fetch_elems(const Shared &sh, long base, const RowCfg &cfg, float2 (&al)[E],
-                                            float (&kth)[E], float (&kph)[E], unsigned &vmask) {
+                                            float (&kw)[E + 1], unsigned &vmask) {
   const int t = threadIdx.x;
-  vmask = 0;
-  float kw[E + 1];
 #pragma unroll
-  for (int e = 0; e <= E; ++e) kw[e] = sh.k_s[pad(t * E + e)];
+  for (int e = 0; e <= E; ++e) kw[e] = sh.u.in.k_s[pad32(t * E + e)];
+  const long first = base + (long)t * E;
+  const long left = cfg.N - first;
+  vmask = left >= E ? 0xFFFFu : (left <= 0 ? 0u : ((1u << (int)left) - 1u));
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    const float av = sh.a_s[pad(t * E + e)];
-    const long gi = base + t * E + e;
-    if (gi < cfg.N) vmask |= (1u << e);
+    const float av = sh.u.in.a_s[pad32(t * E + e)];
     const float xr = av - cfg.z.x;
     const float xi = -cfg.z.y;
     const float n = fmaf(xr, xr, xi * xi);
-    float2 alv;
-    if (n >= 1e-24f) {
-      const float f = fmaf(1e-3f, __builtin_amdgcn_rsqf(n), 1.0f);
-      alv = make_float2(xr * f, xi * f);
-    } else {
-      alv = make_float2(xr + 1e-3f, xi);
-    }
-    al[e] = alv;
-    kth[e] = kw[e];
-    // phi step that produces phi_{i-1} from (phi_i, phi_{i+1}) uses matrix index i: k_{i-1} in the reference's
-    // convention (bk_core.py:171), k_i in the exact one.  At i = N-1 the second term is phi_N = 0.
-    kph[e] = cfg.phi_exact ? ((gi < cfg.N - 1) ? kw[e + 1] : 0.0f) : kw[e];
+    float f = fmaf(1e-3f, __builtin_amdgcn_rsqf(n), 1.0f);
+    float add = 0.0f;
+    if (!(n >= 1e-24f)) { f = 1.0f; add = 1e-3f; }  // |x| < 1e-12: direction taken as 1 (bk_core.py:89-90)
+    al[e] = make_float2(fmaf(xr, f, add), xi * f);
   }
 }
 
 // ---- the forward kernel -------------------------------------------------------------------------------------
-template <typename TIn>
+// lane-state storage: 5 floats per (chunk, thread), laid out [chunk][field][thread]
+template <bool LDS_STATE>
+__device__ __forceinline__ void put_state(float *st, int ch, const Vec &x) {
+  float *p = st + (long)ch * 5 * T + threadIdx.x;
+  p[0] = x.x0.x;
+  p[T] = x.x0.y;
+  p[2 * T] = x.x1.x;
+  p[3 * T] = x.x1.y;
+  p[4 * T] = __int_as_float(x.e);
+}
+template <bool LDS_STATE>
+__device__ __forceinline__ Vec get_state(const float *st, int ch) {
+  const float *p = st + (long)ch * 5 * T + threadIdx.x;
+  Vec x;
+  x.x0.x = p[0];
+  x.x0.y = p[T];
+  x.x1.x = p[2 * T];
+  x.x1.y = p[3 * T];
+  x.e = __float_as_int(p[4 * T]);
+  return x;
+}
+
+template <bool TAIL, int KO_PHI>
+__device__ __forceinline__ void sweepB_chunk(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask,
+                                             const Vec &xt, Vec &p1, Vec &p2, float2 inv_det, int e_det, Shared &sh,
+                                             int &scan_count) {
+  float2 thm[E];
+  int the[E / 2];
+  theta_lane<TAIL>(al, kw, vmask, xt, thm, the);
+  // phi two-pass scan (descending order)
+  Mat A = lane_aggregate<true, TAIL, KO_PHI>(al, kw, vmask);
+  Vec x = block_exclusive<true>(A, p1, sh, scan_count);
+  float k2[E];
+  rerun_wall<true, TAIL, KO_PHI>(al, kw, vmask, x, k2);
+  A = lane_aggregate2<true, TAIL>(al, k2, vmask);
+  x = block_exclusive<true>(A, p2, sh, scan_count);
+  // last phi re-run fused with the epilogue (bk_core.py:190-208); results go to LDS in blocked order.
+  // (all reads of the staged inputs happened before the scans' barriers, so out_s may overwrite them)
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const int ei = E - 1 - j;
+    const float2 P = cmul(cmul(thm[ei], x.x0), inv_det);
+    const int Ee = the[ei >> 1] + x.e - e_det;
+    const float n = fmaf(P.x, P.x, P.y * P.y);
+    const float L = LN2_HALF * fmaf(2.0f, (float)Ee, __builtin_amdgcn_logf(n));  // ln |G_raw|
+    const float sc = ldexpf(__builtin_amdgcn_exp2f(wall_exponent(L) * LOG2E), Ee);
+    // L > 4: exp(88 tanh(L/88)) > 50, the clip makes |G| = 50 (bk_core.py:205-208) whatever the exact magnitude
+    const float f = (L > 4.0f) ? 50.0f * __builtin_amdgcn_rsqf(n) : sc;
+    float2 g = make_float2(P.x * f, P.y * f);
+    const float m2 = fmaf(g.x, g.x, g.y * g.y);
+    const float clip = (m2 > 2500.0f) ? 50.0f * __builtin_amdgcn_rsqf(m2) : 1.0f;
+    g = make_float2(g.x * clip, g.y * clip);
+    if (!(fabsf(g.x) <= 3.0e38f) || !(fabsf(g.y) <= 3.0e38f)) g = make_float2(0.f, 0.f);
+    sh.u.out_s[pad16(t * E + ei)] = g;
+    if (!TAIL || ((vmask >> ei) & 1u)) {
+      const float2 y = rstep(al[ei], k2[ei], x.x0, x.x1);
+      x.x1 = x.x0;
+      x.x0 = y;
+      if ((j & 1) == 1) vnorm(x);
+    }
+  }
+}
+
+// |G| below exp(-22 + wall_exponent(-22)): the series in the epilogue clamped L at -22.  Redo the magnitude
+// with the direct formula (only reachable for |G| < 4.4e-10).
+__device__ __forceinline__ float2 fix_tiny(float2 g) {
+  const float m2 = fmaf(g.x, g.x, g.y * g.y);
+  if (__builtin_expect(m2 < 1.9e-19f && m2 > 0.0f, 0)) {
+    const float g22 = wall_exponent(-WALL_DMAX);
+    const float L = 0.5f * logf(m2) - g22;
+    const float corr = expf(88.0f * tanhf(L * (1.0f / 88.0f)) - L - g22);
+    g = make_float2(g.x * corr, g.y * corr);
+  }
+  return g;
+}
+
+template <typename TIn, bool LDS_STATE, bool PHI_EXACT>
 __global__ __launch_bounds__(T) void bk_forward_kernel(const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_,
                                                        long ldb, const TIn *__restrict__ c_, long ldc,
                                                        const float *__restrict__ z_dev, float z_re, float z_im, long N,
-                                                       float2 *__restrict__ G_, float2 *__restrict__ F_, int *state,
-                                                       int call_id, int fixup, unsigned flags) {
+                                                       float2 *__restrict__ G_, float2 *__restrict__ F_,
+                                                       float *__restrict__ ws, int *state, int call_id, int fixup,
+                                                       unsigned flags) {
   __shared__ Shared sh;
+  __shared__ float lane_state_lds[LDS_STATE ? LDS_STATE_CHUNKS * 5 * T : 1];
   if (fixup) {
     // second launch: only when this call saw a NaN in he_diag AND a NaN in b/c
     const int sa = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -378,41 +492,46 @@ __global__ __launch_bounds__(T) void bk_forward_kernel(const TIn *__restrict__ a
   const TIn *c = c_ + row * ldc;
   float2 *G = G_ + row * N;
   float2 *F = F_ ? F_ + row * N : nullptr;
+  const int nch = (int)((N + CHUNK - 1) / CHUNK);
+  float *st = LDS_STATE ? lane_state_lds : ws + row * (long)nch * 5 * T;
 
   RowCfg cfg;
   cfg.z = z_dev ? make_float2(z_dev[0], z_dev[1]) : make_float2(z_re, z_im);
   cfg.N = N;
   cfg.raw = (flags & BKCORE_FLAG_RAW) != 0;
-  cfg.phi_exact = (flags & BKCORE_FLAG_PHI_EXACT) != 0;
   cfg.fix_bc = fixup != 0;
 
-  const int nch = (int)((N + CHUNK - 1) / CHUNK);
   const int t = threadIdx.x;
   int scan_count = 0;
   unsigned seen = 0;
-
   float2 al[E];
-  float kth[E], kph[E];
-  float2 thm[E], phm[E];
-  int the[E], phe[E];
+  float kw[E + 1];
   unsigned vmask;
 
-  // ---- sweep A: theta carries at chunk boundaries
+  // ---- sweep A: theta; each lane's incoming state per chunk is stored
   Vec c1 = vec_start(), c2 = vec_start();
   for (int ch = 0; ch < nch; ++ch) {
     const long base = (long)ch * CHUNK;
-    if (t == 0) {
-      sh.carry1[ch] = c1;
-      sh.carry2[ch] = c2;
-    }
     __syncthreads();  // previous chunk's LDS reads done
     seen |= stage_chunk<TIn>(a, b, c, base, cfg, sh);
     __syncthreads();
-    fetch_elems(sh, base, cfg, al, kth, kph, vmask);
-    if (base + CHUNK <= N)
-      scan_dir<false, false, false>(al, kth, vmask, c1, c2, thm, the, sh, scan_count);
-    else
-      scan_dir<false, true, false>(al, kth, vmask, c1, c2, thm, the, sh, scan_count);
+    fetch_elems(sh, base, cfg, al, kw, vmask);
+    float k2[E];
+    Vec x;
+    if (base + CHUNK <= N) {
+      Mat A = lane_aggregate<false, false, 0>(al, kw, vmask);
+      x = block_exclusive<false>(A, c1, sh, scan_count);
+      rerun_wall<false, false, 0>(al, kw, vmask, x, k2);
+      A = lane_aggregate2<false, false>(al, k2, vmask);
+      x = block_exclusive<false>(A, c2, sh, scan_count);
+    } else {
+      Mat A = lane_aggregate<false, true, 0>(al, kw, vmask);
+      x = block_exclusive<false>(A, c1, sh, scan_count);
+      rerun_wall<false, true, 0>(al, kw, vmask, x, k2);
+      A = lane_aggregate2<false, true>(al, k2, vmask);
+      x = block_exclusive<false>(A, c2, sh, scan_count);
+    }
+    put_state<LDS_STATE>(st, ch, x);
   }
   // theta_N = first component of the state after the last element
   const float2 dm = c2.x0;
@@ -420,46 +539,28 @@ __global__ __launch_bounds__(T) void bk_forward_kernel(const TIn *__restrict__ a
   const float dn = fmaf(dm.x, dm.x, dm.y * dm.y);
   const float2 inv_det = make_float2(dm.x / dn, -dm.y / dn);
 
-  // ---- sweep B: phi with running carry, theta from saved carries, epilogue
+  // ---- sweep B: phi with running carry, theta from the stored lane states, epilogue, stores
   Vec p1 = vec_start(), p2 = vec_start();
+  constexpr int KO_PHI = PHI_EXACT ? 1 : 0;
   for (int ch = nch - 1; ch >= 0; --ch) {
     const long base = (long)ch * CHUNK;
-    __syncthreads();
+    __syncthreads();  // previous chunk's out_s reads done (and lane states visible)
     stage_chunk<TIn>(a, b, c, base, cfg, sh);
     __syncthreads();
-    fetch_elems(sh, base, cfg, al, kth, kph, vmask);
-    Vec t1 = sh.carry1[ch];
-    Vec t2 = sh.carry2[ch];
-    if (base + CHUNK <= N) {
-      scan_dir<false, false, true>(al, kth, vmask, t1, t2, thm, the, sh, scan_count);
-      scan_dir<true, false, true>(al, kph, vmask, p1, p2, phm, phe, sh, scan_count);
-    } else {
-      scan_dir<false, true, true>(al, kth, vmask, t1, t2, thm, the, sh, scan_count);
-      scan_dir<true, true, true>(al, kph, vmask, p1, p2, phm, phe, sh, scan_count);
-    }
-    // epilogue (bk_core.py:190-208)
+    fetch_elems(sh, base, cfg, al, kw, vmask);
+    const Vec xt = get_state<LDS_STATE>(st, ch);
+    if (base + CHUNK <= N)
+      sweepB_chunk<false, KO_PHI>(al, kw, vmask, xt, p1, p2, inv_det, e_det, sh, scan_count);
+    else
+      sweepB_chunk<true, KO_PHI>(al, kw, vmask, xt, p1, p2, inv_det, e_det, sh, scan_count);
+    __syncthreads();
+    // coalesced stores of G and features (same numbers, bk_core.py:296-298)
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const long gi = base + (long)t * E + e;
-      const float2 P = cmul(cmul(thm[e], phm[e]), inv_det);
-      const int Ee = the[e] + phe[e] - e_det;
-      const float n = fmaf(P.x, P.x, P.y * P.y);
-      const float L = LN2_HALF * fmaf(2.0f, (float)Ee, __builtin_amdgcn_logf(n));  // ln |G_raw|
-      float2 g;
-      if (__builtin_expect(fabsf(L) < 8.0f, 1)) {
-        const float sc = ldexpf(wall_corr(L), Ee);
-        g = make_float2(P.x * sc, P.y * sc);
-      } else {
-        const float mag = expf(88.0f * tanhf(L * (1.0f / 88.0f))) * __builtin_amdgcn_rsqf(n);
-        g = make_float2(P.x * mag, P.y * mag);
-      }
-      if (!(fabsf(g.x) <= 3.0e38f) || !(fabsf(g.y) <= 3.0e38f)) g = make_float2(0.f, 0.f);
-      const float m2 = fmaf(g.x, g.x, g.y * g.y);
-      if (__builtin_expect(m2 > 2500.0f, 0)) {
-        const float f = 50.0f / (sqrtf(m2) + 1e-9f);
-        g = make_float2(g.x * f, g.y * f);
-      }
+    for (int j = 0; j < E; ++j) {
+      const int idx = t + j * T;
+      const long gi = base + idx;
       if (gi < N) {
+        const float2 g = fix_tiny(sh.u.out_s[pad16(idx)]);
         G[gi] = g;
         if (F) F[gi] = g;
       }
@@ -480,7 +581,7 @@ __device__ __forceinline__ float nan_to_num_default(float v) {  // torch.nan_to_
 }
 
 __device__ __forceinline__ float bwd_ref_one(float2 G, float2 g, float alpha) {
-  // g already holds grad wrt (Re G, Im G); conj(g) = (g.x, -g.y)
+  // g holds the cotangent of (Re G, Im G); conj(g) = (g.x, -g.y)
   const float2 g2 = cmul(G, G);
   const float mag = sqrtf(fmaf(g2.x, g2.x, g2.y * g2.y));
   float2 den = g2;
@@ -541,10 +642,12 @@ __global__ __launch_bounds__(256) void bk_backward_ref_kernel(const float2 *__re
 thread_local int g_last_hip_error = 0;
 int g_call_counter = 0;
 
-template <typename TIn>
-int launch_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
-                   const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
-                   void *state, unsigned flags, hipStream_t stream) {
+inline int chunks_of(int64_t N) { return (int)((N + CHUNK - 1) / CHUNK); }
+
+template <typename TIn, bool LDS_STATE, bool PHI_EXACT>
+int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
+                    const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
+                    void *ws, void *state, unsigned flags, hipStream_t stream) {
   int call_id = 0;
   if (state) {
     call_id = __atomic_add_fetch(&g_call_counter, 1, __ATOMIC_RELAXED);
@@ -555,9 +658,9 @@ int launch_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const
   }
   const int launches = (state && !(flags & BKCORE_FLAG_RAW)) ? 2 : 1;
   for (int fixup = 0; fixup < launches; ++fixup) {
-    hipLaunchKernelGGL(bk_forward_kernel<TIn>, dim3((unsigned)B), dim3(T), 0, stream, (const TIn *)a, (long)lda,
-                       (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re, z_im, (long)N, (float2 *)G,
-                       (float2 *)features, (int *)state, call_id, fixup, flags);
+    hipLaunchKernelGGL((bk_forward_kernel<TIn, LDS_STATE, PHI_EXACT>), dim3((unsigned)B), dim3(T), 0, stream,
+                       (const TIn *)a, (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re,
+                       z_im, (long)N, (float2 *)G, (float2 *)features, (float *)ws, (int *)state, call_id, fixup, flags);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
       g_last_hip_error = (int)err;
@@ -567,28 +670,54 @@ int launch_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const
   return BKCORE_OK;
 }
 
+template <typename TIn>
+int launch_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
+                   const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
+                   void *ws, void *state, unsigned flags, hipStream_t s) {
+  const bool lds = chunks_of(N) <= LDS_STATE_CHUNKS;
+  const bool ex = (flags & BKCORE_FLAG_PHI_EXACT) != 0;
+#define BK_GO(L, X) \
+  return launch_forward2<TIn, L, X>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state, flags, s)
+  if (lds) {
+    if (ex) BK_GO(true, true);
+    BK_GO(true, false);
+  }
+  if (ex) BK_GO(false, true);
+  BK_GO(false, false);
+#undef BK_GO
+}
+
 }  // namespace
 
 extern "C" {
 
+size_t bkcore_workspace_bytes(int64_t B, int64_t N) {
+  if (B <= 0 || N <= 0) return 0;
+  const int nch = chunks_of(N);
+  if (nch <= LDS_STATE_CHUNKS) return 0;
+  return (size_t)B * (size_t)nch * 5 * T * sizeof(float);
+}
+
 int bkcore_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc, int in_dtype,
                    const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
-                   void *state, unsigned flags, void *stream) {
+                   void *workspace, size_t workspace_bytes, void *state, unsigned flags, void *stream) {
   if (B < 0 || N < 0 || lda < 0 || ldb < 0 || ldc < 0) return BKCORE_EINVAL;
   if (B == 0 || N == 0) return BKCORE_OK;
   if (!a || !G || (N > 1 && (!b || !c))) return BKCORE_EINVAL;
   if (N > bkcore_max_seq_len()) return BKCORE_ETOOLONG;
   if (B > 2147483647LL) return BKCORE_EINVAL;
+  const size_t need = bkcore_workspace_bytes(B, N);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return BKCORE_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   switch (in_dtype) {
     case BKCORE_F32:
-      return launch_forward<float>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, state, flags, s);
+      return launch_forward<float>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, workspace, state, flags, s);
     case BKCORE_BF16:
-      return launch_forward<uint16_t>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, state, flags, s);
+      return launch_forward<uint16_t>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, workspace, state, flags, s);
     case BKCORE_F16:
-      return launch_forward<_Float16>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, state, flags, s);
+      return launch_forward<_Float16>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, workspace, state, flags, s);
     case BKCORE_F64:
-      return launch_forward<double>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, state, flags, s);
+      return launch_forward<double>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, workspace, state, flags, s);
     default:
       return BKCORE_EINVAL;
   }
@@ -622,9 +751,9 @@ int bkcore_backward_ref(const float *G, const float *grad_features, const float 
   return BKCORE_OK;
 }
 
-int64_t bkcore_max_seq_len(void) { return (int64_t)MAX_CHUNKS * CHUNK; }
+int64_t bkcore_max_seq_len(void) { return (int64_t)MAX_N; }
 int bkcore_last_hip_error(void) { return g_last_hip_error; }
-int bkcore_abi_version(void) { return 1; }
+int bkcore_abi_version(void) { return 2; }
 
 const char *bkcore_error_string(int code) {
   switch (code) {
@@ -632,6 +761,7 @@ const char *bkcore_error_string(int code) {
     case BKCORE_EINVAL: return "invalid argument";
     case BKCORE_ETOOLONG: return "sequence length exceeds bkcore_max_seq_len()";
     case BKCORE_ELAUNCH: return "HIP kernel launch failed (see bkcore_last_hip_error())";
+    case BKCORE_EWORKSPACE: return "workspace missing or smaller than bkcore_workspace_bytes()";
     default: return "unknown bkcore error";
   }
 }

@@ -37,9 +37,14 @@ def test_host_side_argument_checks():
     L = _lib.load()
     assert L.bkcore_abi_version() == _lib.ABI_VERSION
     assert L.bkcore_max_seq_len() >= 1 << 20
-    assert L.bkcore_forward(None, 0, None, 0, None, 0, 0, None, 0.0, 1.0, 4, 16, None, None, None, 0, None) == -1
-    assert L.bkcore_forward(None, 0, None, 0, None, 0, 0, None, 0.0, 1.0, 0, 16, None, None, None, 0, None) == 0
-    assert L.bkcore_forward(None, 0, None, 0, None, 0, 0, None, 0.0, 1.0, -1, 16, None, None, None, 0, None) == -1
+    assert L.bkcore_forward(None, 0, None, 0, None, 0, 0, None, 0.0, 1.0, 4, 16, None, None, None, 0, None, 0, None) == -1
+    assert L.bkcore_forward(None, 0, None, 0, None, 0, 0, None, 0.0, 1.0, 0, 16, None, None, None, 0, None, 0, None) == 0
+    assert L.bkcore_forward(None, 0, None, 0, None, 0, 0, None, 0.0, 1.0, -1, 16, None, None, None, 0, None, 0, None) == -1
+    assert L.bkcore_workspace_bytes(1024, 32768) == 0
+    assert L.bkcore_workspace_bytes(16, 1 << 20) == 16 * 256 * 5 * 256 * 4
+    # a problem that needs scratch is refused without it (checked before any launch)
+    one = ctypes.c_void_p(16)
+    assert L.bkcore_forward(one, 0, one, 0, one, 0, 0, None, 0.0, 1.0, 1, 1 << 20, one, None, None, 0, None, 0, None) == -4
     assert L.bkcore_backward_ref(None, None, None, 0.5, 0, None, None) == 0
     assert L.bkcore_backward_ref(None, None, None, 0.5, 8, None, None) == -1
     assert b"invalid" in L.bkcore_error_string(-1)
