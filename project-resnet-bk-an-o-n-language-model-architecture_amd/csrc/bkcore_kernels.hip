@@ -34,10 +34,19 @@
 namespace {
 
 constexpr int T = 256;             // threads per workgroup
-constexpr int E = 16;              // elements per thread per chunk
+#ifndef BK_E
+#define BK_E 16
+#endif
+constexpr int E = BK_E;            // elements per thread per chunk
 constexpr int CHUNK = T * E;       // elements per chunk
 constexpr int WAVES = T / 64;
-constexpr int LDS_STATE_CHUNKS = 8;  // rows of up to this many chunks keep the lane states in LDS
+#ifndef BK_WAVES_PER_SIMD
+#define BK_WAVES_PER_SIMD 2
+#endif
+#ifndef BK_LDS_STATE_CHUNKS
+#define BK_LDS_STATE_CHUNKS 8
+#endif
+constexpr int LDS_STATE_CHUNKS = BK_LDS_STATE_CHUNKS;  // rows of up to this many chunks keep the lane states in LDS
 constexpr long MAX_N = 1L << 24;
 constexpr float LN2_HALF = 0.34657359027997264f;  // 0.5 * ln 2
 constexpr float LOG2E = 1.4426950408889634f;
@@ -118,19 +127,51 @@ __device__ __forceinline__ Vec vec_start() {  // (1, 0): theta_0 = 1, theta_{-1}
   v.e = 0;
   return v;
 }
-__device__ __forceinline__ Mat mat_shfl(const Mat &m, int src) {
+// p * q without renormalisation (exponents add); callers bound the growth
+__device__ __forceinline__ Mat matmul_raw(const Mat &p, const Mat &q) {
   Mat r;
-  r.a.x = __shfl(m.a.x, src);
-  r.a.y = __shfl(m.a.y, src);
-  r.b.x = __shfl(m.b.x, src);
-  r.b.y = __shfl(m.b.y, src);
-  r.c.x = __shfl(m.c.x, src);
-  r.c.y = __shfl(m.c.y, src);
-  r.d.x = __shfl(m.d.x, src);
-  r.d.y = __shfl(m.d.y, src);
-  r.e = __shfl(m.e, src);
+  r.a = cmad(cmul(p.a, q.a), p.b, q.c);
+  r.b = cmad(cmul(p.a, q.b), p.b, q.d);
+  r.c = cmad(cmul(p.c, q.a), p.d, q.c);
+  r.d = cmad(cmul(p.c, q.b), p.d, q.d);
+  r.e = p.e + q.e;
   return r;
 }
+__device__ __forceinline__ Vec matvec_raw(const Mat &p, const Vec &v) {
+  Vec r;
+  r.x0 = cmad(cmul(p.a, v.x0), p.b, v.x1);
+  r.x1 = cmad(cmul(p.c, v.x0), p.d, v.x1);
+  r.e = p.e + v.e;
+  return r;
+}
+
+// Cross-lane moves by DPP (v_mov_b32_dpp): lanes without a source keep `old`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float src) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int old, int src) {
+  return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xF, false);
+}
+// The matrix of the lane selected by CTRL; identity where the selection has no source lane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Mat mat_dpp(const Mat &m) {
+  Mat r;
+  r.a.x = dpp_f<CTRL, ROW_MASK>(1.0f, m.a.x);
+  r.a.y = dpp_f<CTRL, ROW_MASK>(0.0f, m.a.y);
+  r.b.x = dpp_f<CTRL, ROW_MASK>(0.0f, m.b.x);
+  r.b.y = dpp_f<CTRL, ROW_MASK>(0.0f, m.b.y);
+  r.c.x = dpp_f<CTRL, ROW_MASK>(0.0f, m.c.x);
+  r.c.y = dpp_f<CTRL, ROW_MASK>(0.0f, m.c.y);
+  r.d.x = dpp_f<CTRL, ROW_MASK>(1.0f, m.d.x);
+  r.d.y = dpp_f<CTRL, ROW_MASK>(0.0f, m.d.y);
+  r.e = dpp_i<CTRL, ROW_MASK>(0, m.e);
+  return r;
+}
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHR1 = 0x138;
 
 // exp(88 tanh(d/88) - d): the reference's soft clamp exp(88 tanh(d/88)) (bk_core.py:60-75) relative to exp(d).
 // Branch-free: tanh series to u^11 (relative error of the exponent < 2e-6 for |d| <= 22); |d| is clamped to 22
@@ -146,11 +187,9 @@ __device__ __forceinline__ float wall_exponent(float d) {
   p = fmaf(s, p, 1.0f / 3.0f);
   return -88.0f * u * s * p;
 }
-__device__ __forceinline__ float wall_corr(float d) {
-  float w = __builtin_amdgcn_exp2f(wall_exponent(d) * LOG2E);
-  if (!(fabsf(d) <= 3.0e38f)) w = 1.0f;
-  return w;
-}
+// (a non-finite d only arises next to an exactly zero term, whose product with the factor is zero anyway;
+//  the clamp keeps the factor finite)
+__device__ __forceinline__ float wall_corr(float d) { return __builtin_amdgcn_exp2f(wall_exponent(d) * LOG2E); }
 
 constexpr int A_PAD = CHUNK + CHUNK / 32 + 8;
 constexpr int O_PAD = CHUNK + CHUNK / 16 + 8;
@@ -164,6 +203,7 @@ struct Shared {
     float2 out_s[O_PAD];      // G of one chunk, index idx + idx/16, for coalesced stores
   } u;
   Mat tot[2][WAVES];          // per-wave aggregates, double-buffered across scans
+  Vec carry[2][2];            // running chunk carries (pass 1 / pass 2), double-buffered across chunks
 };
 
 __device__ __forceinline__ int pad32(int idx) { return idx + (idx >> 5); }
@@ -173,60 +213,51 @@ __device__ __forceinline__ int pad16(int idx) { return idx + (idx >> 4); }
 // Element order inside a lane: ascending for theta, descending (REV) for phi.  kw holds k_{i-1} for the lane's
 // elements plus one more (k of the lane's last element); KO selects which one a step uses.
 
-// Product of the lane's E transfer matrices in processing order.
+// One more element folded into the running product A <- M(al, k) * A.
+__device__ __forceinline__ void agg_step(Mat &A, float2 al, float k) {
+  const float2 na = rstep(al, k, A.a, A.c);
+  const float2 nb = rstep(al, k, A.b, A.d);
+  A.c = A.a;
+  A.d = A.b;
+  A.a = na;
+  A.b = nb;
+}
+
+// Pass 1: product of the lane's E transfer matrices (linear recurrence, plain k) in processing order.
+// Renormalised every 4 elements: one step grows an entry by at most |alpha| + |k| (2^7.7 for clamped inputs).
 template <bool REV, bool TAIL, int KO>
 __device__ __forceinline__ Mat lane_aggregate(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask) {
   Mat A = mat_identity();
 #pragma unroll
   for (int j = 0; j < E; ++j) {
     const int ei = REV ? E - 1 - j : j;
-    if (!TAIL || ((vmask >> ei) & 1u)) {
-      const float2 na = rstep(al[ei], kw[ei + KO], A.a, A.c);
-      const float2 nb = rstep(al[ei], kw[ei + KO], A.b, A.d);
-      A.c = A.a;
-      A.d = A.b;
-      A.a = na;
-      A.b = nb;
-    }
-    if ((j & 1) == 1) mnorm(A);
-  }
-  return A;
-}
-template <bool REV, bool TAIL>
-__device__ __forceinline__ Mat lane_aggregate2(const float2 (&al)[E], const float (&k2)[E], unsigned vmask) {
-  Mat A = mat_identity();
-#pragma unroll
-  for (int j = 0; j < E; ++j) {
-    const int ei = REV ? E - 1 - j : j;
-    if (!TAIL || ((vmask >> ei) & 1u)) {
-      const float2 na = rstep(al[ei], k2[ei], A.a, A.c);
-      const float2 nb = rstep(al[ei], k2[ei], A.b, A.d);
-      A.c = A.a;
-      A.d = A.b;
-      A.a = na;
-      A.b = nb;
-    }
-    if ((j & 1) == 1) mnorm(A);
+    if (!TAIL || ((vmask >> ei) & 1u)) agg_step(A, al[ei], kw[ei + KO]);
+    if ((j & 3) == 3) mnorm(A);
   }
   return A;
 }
 
-// Pass-1 re-run from the lane's incoming state: wall factor per element -> k2 = k * w.
+// Pass 2 set-up, three independent chains in one loop: the linear recurrence re-run from the lane's incoming
+// pass-1 state gives d_p and so the wall factor; k2 = k * w is recorded and folded straight into the pass-2
+// product of the lane.
 template <bool REV, bool TAIL, int KO>
-__device__ __forceinline__ void rerun_wall(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask, Vec x,
-                                           float (&k2)[E]) {
+__device__ __forceinline__ Mat wall_and_aggregate(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask,
+                                                  Vec x, float (&k2)[E]) {
+  Mat A = mat_identity();
   float l0 = log2_norm2(x.x0);
   float l1 = log2_norm2(x.x1);
 #pragma unroll
   for (int j = 0; j < E; ++j) {
     const int ei = REV ? E - 1 - j : j;
     const float d = LN2_HALF * (l1 - l0);  // ln|prev2| - ln|prev|
-    k2[ei] = kw[ei + KO] * wall_corr(d);
+    const float kk = kw[ei + KO] * wall_corr(d);
+    k2[ei] = kk;
     if (!TAIL || ((vmask >> ei) & 1u)) {
       const float2 y = rstep(al[ei], kw[ei + KO], x.x0, x.x1);
       x.x1 = x.x0;
       x.x0 = y;
       l1 = l0;
+      agg_step(A, al[ei], kk);
       if ((j & 1) == 1) {
         const int de = expo(fmaxf(amax2(x.x0), amax2(x.x1)));
         x.x0 = ld2(x.x0, -de);
@@ -235,16 +266,23 @@ __device__ __forceinline__ void rerun_wall(const float2 (&al)[E], const float (&
       }
       l0 = log2_norm2(x.x0);
     }
+    if ((j & 3) == 3) mnorm(A);
   }
+  return A;
 }
 
-// theta inside one lane from its exact incoming state: the non-linear recurrence itself (wall factor from the
-// running state, as bk_core.py:116-140 does).  Outputs theta_i mantissas; exponents are shared by element pairs.
+// theta inside one lane from its stored incoming (pass-2) state, two chains in lockstep: a linear one that
+// only supplies d_p for the wall factor (kept off the critical path) and the wall-corrected one whose terms
+// are the outputs.  Both start from the same state (their ratio of consecutive terms agrees to ~1e-5, far
+// tighter than the wall factor needs) and share the rescaling exponent.  The mantissas go to the lane's 16 slots
+// of the LDS output tile (`om`, consecutive), where the epilogue later replaces each by G in place; exponents
+// are shared by element pairs and stay in registers.
 template <bool TAIL>
 __device__ __forceinline__ void theta_lane(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask, Vec x,
-                                           float2 (&om)[E], int (&oe)[E / 2]) {
-  float l0 = log2_norm2(x.x0);
-  float l1 = log2_norm2(x.x1);
+                                           float2 *__restrict__ om, int (&oe)[E / 2]) {
+  float2 u0 = x.x0, u1 = x.x1;  // linear chain
+  float l0 = log2_norm2(u0);
+  float l1 = log2_norm2(u1);
 #pragma unroll
   for (int j = 0; j < E; ++j) {
     om[j] = x.x0;
@@ -252,7 +290,10 @@ __device__ __forceinline__ void theta_lane(const float2 (&al)[E], const float (&
     const float d = LN2_HALF * (l1 - l0);
     const float kk = kw[j] * wall_corr(d);
     if (!TAIL || ((vmask >> j) & 1u)) {
+      const float2 yu = rstep(al[j], kw[j], u0, u1);
       const float2 y = rstep(al[j], kk, x.x0, x.x1);
+      u1 = u0;
+      u0 = yu;
       x.x1 = x.x0;
       x.x0 = y;
       l1 = l0;
@@ -260,46 +301,51 @@ __device__ __forceinline__ void theta_lane(const float2 (&al)[E], const float (&
         const int de = expo(fmaxf(amax2(x.x0), amax2(x.x1)));
         x.x0 = ld2(x.x0, -de);
         x.x1 = ld2(x.x1, -de);
+        u0 = ld2(u0, -de);
+        u1 = ld2(u1, -de);
         x.e += de;
         l1 -= 2.0f * (float)de;
       }
-      l0 = log2_norm2(x.x0);
+      l0 = log2_norm2(u0);
     }
   }
 }
 
 // ---- workgroup-level exclusive scan of lane aggregates ------------------------------------------------------
-// Returns this lane's incoming state (product of all earlier lanes' aggregates applied to `carry`) and advances
-// `carry` across the whole chunk.  "Earlier" follows the processing order: ascending threads, or descending if REV.
-template <bool REV>
-__device__ __forceinline__ Vec block_exclusive(Mat A, Vec &carry, Shared &sh, int &scan_count) {
+// Lanes are scanned in ascending thread order.  Returns this lane's incoming state (product of all earlier
+// lanes' aggregates applied to the running carry `which`, kept in LDS) and advances that carry across the chunk.
+// Scans alternate between carry 0 (pass 1) and carry 1 (pass 2).
+// Wave level: Kogge-Stone over DPP moves (row_shr 1,2,4,8 inside 16-lane rows, then row_bcast 15 / 31 carry the
+// row totals upward); lanes without a source combine with the identity.  Normalised inputs (largest component
+// in [0.5,1)) let two products go by between renormalisations: |entry| <= 2^0.5 -> 2^2 -> 2^5.
+__device__ __forceinline__ Vec block_exclusive(Mat A, int which, Shared &sh, int &scan_count) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  // inclusive Kogge-Stone scan inside the wave
-#pragma unroll
-  for (int s = 1; s < 64; s <<= 1) {
-    const int src = REV ? lane + s : lane - s;
-    const Mat o = mat_shfl(A, src & 63);
-    const Mat cmb = matmul(A, o);
-    const bool take = REV ? (lane + s < 64) : (lane >= s);
-    if (take) A = cmb;
-  }
+  A = matmul_raw(A, mat_dpp<DPP_ROW_SHR1, 0xF>(A));
+  A = matmul(A, mat_dpp<DPP_ROW_SHR2, 0xF>(A));
+  A = matmul_raw(A, mat_dpp<DPP_ROW_SHR4, 0xF>(A));
+  A = matmul(A, mat_dpp<DPP_ROW_SHR8, 0xF>(A));
+  A = matmul_raw(A, mat_dpp<DPP_ROW_BCAST15, 0xA>(A));
+  A = matmul(A, mat_dpp<DPP_ROW_BCAST31, 0xC>(A));
+  // each carry is used by every second scan; its two slots alternate so that the new value never
+  // overwrites one that a slower wave may still be reading (a barrier of another scan lies in between)
   const int buf = scan_count & 1;
+  const int par = (scan_count >> 1) & 1;
   scan_count++;
-  if (lane == (REV ? 0 : 63)) sh.tot[buf][wave] = A;
-  // exclusive prefix inside the wave
-  Mat ex = mat_shfl(A, (REV ? lane + 1 : lane - 1) & 63);
-  if (lane == (REV ? 63 : 0)) ex = mat_identity();
+  if (lane == 63) sh.tot[buf][wave] = A;
+  const Mat ex = mat_dpp<DPP_WAVE_SHR1, 0xF>(A);  // exclusive prefix inside the wave (identity in lane 0)
   __syncthreads();
-  Vec v = carry;
-  Vec xin = carry;
+  Vec v = sh.carry[which][par];
+  Vec xin = v;
 #pragma unroll
   for (int w = 0; w < WAVES; ++w) {
-    const int wi = REV ? WAVES - 1 - w : w;
-    if (wi == wave) xin = v;
-    v = matvec(sh.tot[buf][wi], v);
+    if (w == wave) xin = v;
+    v = matvec_raw(sh.tot[buf][w], v);  // four un-normalised products grow a component by at most 2^8
   }
-  carry = v;
+  if (threadIdx.x == 0) {
+    vnorm(v);
+    sh.carry[which][par ^ 1] = v;
+  }
   return matvec(ex, xin);
 }
 
@@ -331,40 +377,44 @@ __device__ __forceinline__ unsigned stage_chunk(const TIn *__restrict__ a, const
                                                 const TIn *__restrict__ c, long base, const RowCfg &cfg, Shared &sh) {
   unsigned seen = 0;
   const int t = threadIdx.x;
-  float av[E], bv[E + 1], cv[E + 1];
-  // issue all global loads first, then convert / sanitise / write to LDS
+  {
+    float av[E];
 #pragma unroll
-  for (int j = 0; j < E; ++j) {
-    const long gi = base + t + j * T;
-    av[j] = (gi < cfg.N) ? to_f32<TIn>(a[gi]) : 1.0f;
-  }
-#pragma unroll
-  for (int j = 0; j <= E; ++j) {
-    const long g = base - 1 + t + j * T;
-    const bool ok = (j < E || t == 0) && g >= 0 && g < cfg.N - 1;
-    bv[j] = ok ? to_f32<TIn>(b[g]) : 0.0f;
-    cv[j] = ok ? to_f32<TIn>(c[g]) : 0.0f;
-  }
-#pragma unroll
-  for (int j = 0; j < E; ++j) {
-    float v = av[j];
-    if (!cfg.raw) {
-      v = clamp_keep_nan(v, 100.0f);
-      if (v != v) { v = 0.0f; seen |= 1u; }
+    for (int j = 0; j < E; ++j) {
+      const long gi = base + t + j * T;
+      av[j] = (gi < cfg.N) ? to_f32<TIn>(a[gi]) : 1.0f;
     }
-    sh.u.in.a_s[pad32(t + j * T)] = v;
-  }
 #pragma unroll
-  for (int j = 0; j <= E; ++j) {
-    if (j < E || t == 0) {
-      float p = bv[j], q = cv[j];
+    for (int j = 0; j < E; ++j) {
+      float v = av[j];
       if (!cfg.raw) {
-        p = clamp_keep_nan(p, 10.0f);
-        q = clamp_keep_nan(q, 10.0f);
-        if (p != p) { seen |= 2u; if (cfg.fix_bc) p = 1.0f; }
-        if (q != q) { seen |= 2u; if (cfg.fix_bc) q = 1.0f; }
+        v = clamp_keep_nan(v, 100.0f);
+        if (v != v) { v = 0.0f; seen |= 1u; }
       }
-      sh.u.in.k_s[pad32(t + j * T)] = p * q;
+      sh.u.in.a_s[pad32(t + j * T)] = v;
+    }
+  }
+  {
+    float bv[E + 1], cv[E + 1];
+#pragma unroll
+    for (int j = 0; j <= E; ++j) {
+      const long g = base - 1 + t + j * T;
+      const bool ok = (j < E || t == 0) && g >= 0 && g < cfg.N - 1;
+      bv[j] = ok ? to_f32<TIn>(b[g]) : 0.0f;
+      cv[j] = ok ? to_f32<TIn>(c[g]) : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j <= E; ++j) {
+      if (j < E || t == 0) {
+        float p = bv[j], q = cv[j];
+        if (!cfg.raw) {
+          p = clamp_keep_nan(p, 10.0f);
+          q = clamp_keep_nan(q, 10.0f);
+          if (p != p) { seen |= 2u; if (cfg.fix_bc) p = 1.0f; }
+          if (q != q) { seen |= 2u; if (cfg.fix_bc) q = 1.0f; }
+        }
+        sh.u.in.k_s[pad32(t + j * T)] = p * q;
+      }
     }
   }
   return seen;
@@ -372,17 +422,18 @@ __device__ __forceinline__ unsigned stage_chunk(const TIn *__restrict__ a, const
 
 // Reads the thread's E elements back in blocked order and forms alpha = reg(a - z) (bk_core.py:78-94) and
 // kw[e] = k_{i-1} for i = first element + e, e = 0..E.
-__device__ __forceinline__ void fetch_elems(const Shared &sh, long base, const RowCfg &cfg, float2 (&al)[E],
+// `seg` is the 16-element segment of the chunk this thread owns (thread t in sweep A, T-1-t in sweep B, so that
+// the phi scan also runs over ascending threads).
+__device__ __forceinline__ void fetch_elems(const Shared &sh, long base, int seg, const RowCfg &cfg, float2 (&al)[E],
                                             float (&kw)[E + 1], unsigned &vmask) {
-  const int t = threadIdx.x;
 #pragma unroll
-  for (int e = 0; e <= E; ++e) kw[e] = sh.u.in.k_s[pad32(t * E + e)];
-  const long first = base + (long)t * E;
+  for (int e = 0; e <= E; ++e) kw[e] = sh.u.in.k_s[pad32(seg * E + e)];
+  const long first = base + (long)seg * E;
   const long left = cfg.N - first;
-  vmask = left >= E ? 0xFFFFu : (left <= 0 ? 0u : ((1u << (int)left) - 1u));
+  vmask = left >= E ? ((1u << E) - 1u) : (left <= 0 ? 0u : ((1u << (int)left) - 1u));
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    const float av = sh.u.in.a_s[pad32(t * E + e)];
+    const float av = sh.u.in.a_s[pad32(seg * E + e)];
     const float xr = av - cfg.z.x;
     const float xi = -cfg.z.y;
     const float n = fmaf(xr, xr, xi * xi);
@@ -396,8 +447,8 @@ __device__ __forceinline__ void fetch_elems(const Shared &sh, long base, const R
 // ---- the forward kernel -------------------------------------------------------------------------------------
 // lane-state storage: 5 floats per (chunk, thread), laid out [chunk][field][thread]
 template <bool LDS_STATE>
-__device__ __forceinline__ void put_state(float *st, int ch, const Vec &x) {
-  float *p = st + (long)ch * 5 * T + threadIdx.x;
+__device__ __forceinline__ void put_state(float *st, int ch, int seg, const Vec &x) {
+  float *p = st + (long)ch * 5 * T + seg;
   p[0] = x.x0.x;
   p[T] = x.x0.y;
   p[2 * T] = x.x1.x;
@@ -405,8 +456,8 @@ __device__ __forceinline__ void put_state(float *st, int ch, const Vec &x) {
   p[4 * T] = __int_as_float(x.e);
 }
 template <bool LDS_STATE>
-__device__ __forceinline__ Vec get_state(const float *st, int ch) {
-  const float *p = st + (long)ch * 5 * T + threadIdx.x;
+__device__ __forceinline__ Vec get_state(const float *st, int ch, int seg) {
+  const float *p = st + (long)ch * 5 * T + seg;
   Vec x;
   x.x0.x = p[0];
   x.x0.y = p[T];
@@ -418,25 +469,23 @@ __device__ __forceinline__ Vec get_state(const float *st, int ch) {
 
 template <bool TAIL, int KO_PHI>
 __device__ __forceinline__ void sweepB_chunk(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask,
-                                             const Vec &xt, Vec &p1, Vec &p2, float2 inv_det, int e_det, Shared &sh,
-                                             int &scan_count) {
-  float2 thm[E];
-  int the[E / 2];
-  theta_lane<TAIL>(al, kw, vmask, xt, thm, the);
-  // phi two-pass scan (descending order)
+                                             const Vec &xt, float2 inv_det, int e_det, Shared &sh, int &scan_count,
+                                             int seg) {
   Mat A = lane_aggregate<true, TAIL, KO_PHI>(al, kw, vmask);
-  Vec x = block_exclusive<true>(A, p1, sh, scan_count);
+  Vec x = block_exclusive(A, 0, sh, scan_count);
   float k2[E];
-  rerun_wall<true, TAIL, KO_PHI>(al, kw, vmask, x, k2);
-  A = lane_aggregate2<true, TAIL>(al, k2, vmask);
-  x = block_exclusive<true>(A, p2, sh, scan_count);
-  // last phi re-run fused with the epilogue (bk_core.py:190-208); results go to LDS in blocked order.
-  // (all reads of the staged inputs happened before the scans' barriers, so out_s may overwrite them)
-  const int t = threadIdx.x;
+  A = wall_and_aggregate<true, TAIL, KO_PHI>(al, kw, vmask, x, k2);
+  x = block_exclusive(A, 1, sh, scan_count);
+  // theta of the lane's elements into the lane's slots of the output tile.  (All reads of the staged inputs
+  // happened before the scans' barriers, so the tile may overwrite them; each slot is touched by this thread only.)
+  float2 *slot = &sh.u.out_s[pad16(seg * E)];
+  int the[E / 2];
+  theta_lane<TAIL>(al, kw, vmask, xt, slot, the);
+  // last phi re-run fused with the epilogue (bk_core.py:190-208): theta_i in the slot is replaced by G_i
 #pragma unroll
   for (int j = 0; j < E; ++j) {
     const int ei = E - 1 - j;
-    const float2 P = cmul(cmul(thm[ei], x.x0), inv_det);
+    const float2 P = cmul(cmul(slot[ei], x.x0), inv_det);
     const int Ee = the[ei >> 1] + x.e - e_det;
     const float n = fmaf(P.x, P.x, P.y * P.y);
     const float L = LN2_HALF * fmaf(2.0f, (float)Ee, __builtin_amdgcn_logf(n));  // ln |G_raw|
@@ -448,7 +497,7 @@ __device__ __forceinline__ void sweepB_chunk(const float2 (&al)[E], const float 
     const float clip = (m2 > 2500.0f) ? 50.0f * __builtin_amdgcn_rsqf(m2) : 1.0f;
     g = make_float2(g.x * clip, g.y * clip);
     if (!(fabsf(g.x) <= 3.0e38f) || !(fabsf(g.y) <= 3.0e38f)) g = make_float2(0.f, 0.f);
-    sh.u.out_s[pad16(t * E + ei)] = g;
+    slot[ei] = g;
     if (!TAIL || ((vmask >> ei) & 1u)) {
       const float2 y = rstep(al[ei], k2[ei], x.x0, x.x1);
       x.x1 = x.x0;
@@ -472,14 +521,14 @@ __device__ __forceinline__ float2 fix_tiny(float2 g) {
 }
 
 template <typename TIn, bool LDS_STATE, bool PHI_EXACT>
-__global__ __launch_bounds__(T) void bk_forward_kernel(const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_,
+__global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_,
                                                        long ldb, const TIn *__restrict__ c_, long ldc,
                                                        const float *__restrict__ z_dev, float z_re, float z_im, long N,
                                                        float2 *__restrict__ G_, float2 *__restrict__ F_,
                                                        float *__restrict__ ws, int *state, int call_id, int fixup,
                                                        unsigned flags) {
   __shared__ Shared sh;
-  __shared__ float lane_state_lds[LDS_STATE ? LDS_STATE_CHUNKS * 5 * T : 1];
+  __shared__ float lane_state_lds[(LDS_STATE && LDS_STATE_CHUNKS > 0) ? LDS_STATE_CHUNKS * 5 * T : 1];
   if (fixup) {
     // second launch: only when this call saw a NaN in he_diag AND a NaN in b/c
     const int sa = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -509,50 +558,58 @@ __global__ __launch_bounds__(T) void bk_forward_kernel(const TIn *__restrict__ a
   unsigned vmask;
 
   // ---- sweep A: theta; each lane's incoming state per chunk is stored
-  Vec c1 = vec_start(), c2 = vec_start();
+  if (t == 0) {
+    sh.carry[0][0] = vec_start();
+    sh.carry[1][0] = vec_start();
+  }
   for (int ch = 0; ch < nch; ++ch) {
     const long base = (long)ch * CHUNK;
     __syncthreads();  // previous chunk's LDS reads done
     seen |= stage_chunk<TIn>(a, b, c, base, cfg, sh);
     __syncthreads();
-    fetch_elems(sh, base, cfg, al, kw, vmask);
+    fetch_elems(sh, base, t, cfg, al, kw, vmask);
     float k2[E];
     Vec x;
     if (base + CHUNK <= N) {
       Mat A = lane_aggregate<false, false, 0>(al, kw, vmask);
-      x = block_exclusive<false>(A, c1, sh, scan_count);
-      rerun_wall<false, false, 0>(al, kw, vmask, x, k2);
-      A = lane_aggregate2<false, false>(al, k2, vmask);
-      x = block_exclusive<false>(A, c2, sh, scan_count);
+      x = block_exclusive(A, 0, sh, scan_count);
+      A = wall_and_aggregate<false, false, 0>(al, kw, vmask, x, k2);
+      x = block_exclusive(A, 1, sh, scan_count);
     } else {
       Mat A = lane_aggregate<false, true, 0>(al, kw, vmask);
-      x = block_exclusive<false>(A, c1, sh, scan_count);
-      rerun_wall<false, true, 0>(al, kw, vmask, x, k2);
-      A = lane_aggregate2<false, true>(al, k2, vmask);
-      x = block_exclusive<false>(A, c2, sh, scan_count);
+      x = block_exclusive(A, 0, sh, scan_count);
+      A = wall_and_aggregate<false, true, 0>(al, kw, vmask, x, k2);
+      x = block_exclusive(A, 1, sh, scan_count);
     }
-    put_state<LDS_STATE>(st, ch, x);
+    put_state<LDS_STATE>(st, ch, t, x);
   }
-  // theta_N = first component of the state after the last element
-  const float2 dm = c2.x0;
-  const int e_det = c2.e;
+  // theta_N = first component of the pass-2 state after the last element
+  __syncthreads();
+  const Vec cdet = sh.carry[1][(scan_count >> 1) & 1];
+  const float2 dm = cdet.x0;
+  const int e_det = cdet.e;
   const float dn = fmaf(dm.x, dm.x, dm.y * dm.y);
   const float2 inv_det = make_float2(dm.x / dn, -dm.y / dn);
+  __syncthreads();
 
   // ---- sweep B: phi with running carry, theta from the stored lane states, epilogue, stores
-  Vec p1 = vec_start(), p2 = vec_start();
+  if (t == 0) {
+    sh.carry[0][(scan_count >> 1) & 1] = vec_start();
+    sh.carry[1][(scan_count >> 1) & 1] = vec_start();
+  }
   constexpr int KO_PHI = PHI_EXACT ? 1 : 0;
   for (int ch = nch - 1; ch >= 0; --ch) {
     const long base = (long)ch * CHUNK;
     __syncthreads();  // previous chunk's out_s reads done (and lane states visible)
     stage_chunk<TIn>(a, b, c, base, cfg, sh);
     __syncthreads();
-    fetch_elems(sh, base, cfg, al, kw, vmask);
-    const Vec xt = get_state<LDS_STATE>(st, ch);
+    const int seg = T - 1 - t;  // descending segments over ascending threads: phi's processing order
+    fetch_elems(sh, base, seg, cfg, al, kw, vmask);
+    const Vec xt = get_state<LDS_STATE>(st, ch, seg);
     if (base + CHUNK <= N)
-      sweepB_chunk<false, KO_PHI>(al, kw, vmask, xt, p1, p2, inv_det, e_det, sh, scan_count);
+      sweepB_chunk<false, KO_PHI>(al, kw, vmask, xt, inv_det, e_det, sh, scan_count, seg);
     else
-      sweepB_chunk<true, KO_PHI>(al, kw, vmask, xt, p1, p2, inv_det, e_det, sh, scan_count);
+      sweepB_chunk<true, KO_PHI>(al, kw, vmask, xt, inv_det, e_det, sh, scan_count, seg);
     __syncthreads();
     // coalesced stores of G and features (same numbers, bk_core.py:296-298)
 #pragma unroll
