@@ -63,21 +63,23 @@ extern "C" {
  *    device tensor, src/models/resnet_bk.py:159-161) or the host values z_re, z_im.
  * G: B*N interleaved (re, im) float pairs = complex64, row-major.  Required.
  * features: B*N*2 floats, the same numbers as G (src/models/bk_core.py:296-298), or NULL to skip.
- * state: BKCORE_STATE_BYTES of zero-initialised persistent device memory, or NULL.  It is used only to
- *    reproduce one corner of the reference's sanitiser without a host sync: NaNs in b or c are replaced
- *    by 1 only when he_diag holds a NaN somewhere in the batch (src/models/bk_core.py:260-264).  With
- *    state == NULL NaNs in b/c are never replaced (such rows then come out as zeros, as in the reference
- *    when he_diag is clean).
- * workspace: device scratch of at least bkcore_workspace_bytes(B, N) bytes (16-byte aligned), owned by the caller
- *    and free to reuse as soon as the stream has passed this call; may be NULL when that size is 0.
+ * state: BKCORE_STATE_BYTES of zero-initialised persistent device memory (one block per device and stream,
+ *    reused by every call), or NULL.  It carries two verdicts from the first kernel launch of a call to its second
+ *    one without a host sync: (1) the first launch takes a shortcut for the scan that only feeds the reference's
+ *    in-recurrence soft clamp, checks it per row, and rows that fail the check are recomputed by the full two-scan
+ *    path in the second launch; (2) NaNs in b or c are replaced by 1 only when he_diag holds a NaN somewhere in the
+ *    batch (src/models/bk_core.py:260-264).  With state == NULL there is a single launch on the full two-scan path
+ *    and NaNs in b/c are never replaced (such rows come out as zeros, as in the reference when he_diag is clean).
+ * workspace: device scratch of at least bkcore_workspace_bytes(B, N) bytes (256-byte aligned), owned by the caller
+ *    and free to reuse as soon as the stream has passed this call.
  */
 int bkcore_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc, int in_dtype,
                    const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
                    void *workspace, size_t workspace_bytes, void *state, unsigned flags, void *stream);
 
-/* Scratch bytes bkcore_forward needs for a (B, N) problem: 0 for N <= 32768 (per-lane scan states stay in LDS),
- * otherwise 20 bytes per 16 elements (rounded up to whole 4096-element chunks).  No counterpart in the reference,
- * which allocates its theta/phi buffers inside the call (src/kernels/bk_scan.py:416-417). */
+/* Scratch bytes bkcore_forward needs for a (B, N) problem: 4 bytes per row plus 20 bytes per 16 elements (rounded up
+ * to whole 4096-element chunks).  No counterpart in the reference, which allocates its theta/phi buffers inside the
+ * call (src/kernels/bk_scan.py:416-417). */
 size_t bkcore_workspace_bytes(int64_t B, int64_t N);
 
 /*

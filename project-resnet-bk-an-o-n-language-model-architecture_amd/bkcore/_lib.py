@@ -13,7 +13,7 @@ F32, BF16, F16, F64 = 0, 1, 2, 3
 FLAG_RAW = 1
 FLAG_PHI_EXACT = 2
 STATE_BYTES = 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EXPORTS = ("bkcore_forward", "bkcore_workspace_bytes", "bkcore_backward_ref", "bkcore_max_seq_len", "bkcore_last_hip_error",
            "bkcore_error_string", "bkcore_abi_version")

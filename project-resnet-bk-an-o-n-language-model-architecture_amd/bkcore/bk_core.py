@@ -26,6 +26,7 @@ from . import _lib
 logger = logging.getLogger(__name__)
 
 _DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16, torch.float64: _lib.F64}
+_DEBUG = {"keep_ws": False, "last_ws": None, "last_B": 0}  # diagnostics: see rows_recomputed()
 _state = {}  # (device index, stream handle) -> persistent int32 state block for the NaN-sanitiser corner
 
 
@@ -104,7 +105,7 @@ def bk_forward(a, b, c, z, raw: bool = False, phi_exact: bool = False, want_feat
     with torch.cuda.device(a.device):
         stream = torch.cuda.current_stream().cuda_stream
         zkeep, pz, zre, zim = _prep_z(z, a.device)
-        state = None if raw else _state_block(a.device, stream)
+        state = _state_block(a.device, stream)
         flags = (_lib.FLAG_RAW if raw else 0) | (_lib.FLAG_PHI_EXACT if phi_exact else 0)
         ws_bytes = int(L.bkcore_workspace_bytes(B, N))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
@@ -114,7 +115,18 @@ def bk_forward(a, b, c, z, raw: bool = False, phi_exact: bool = False, want_feat
                               state.data_ptr() if state is not None else None, flags, stream)
     _lib.check(rc, "bkcore_forward")
     del zkeep
+    if _DEBUG["keep_ws"]:
+        _DEBUG["last_ws"], _DEBUG["last_B"] = ws, B
     return feats, G
+
+
+def rows_recomputed():
+    """Diagnostics: number of rows of the last forward (run with _DEBUG['keep_ws'] = True) whose fast first pass
+    failed its check and that the second launch recomputed on the two-scan path."""
+    ws, B = _DEBUG["last_ws"], _DEBUG["last_B"]
+    if ws is None:
+        return None
+    return int(ws[: 4 * B].view(torch.int32).ne(0).sum().item())
 
 
 def bk_backward_reference(G, grad_features, grad_G, alpha: float):

@@ -21,11 +21,13 @@
 //
 // Kernel shape: one workgroup of 256 threads per row, chunks of 256 x 16 elements, each thread
 // owning 16 consecutive elements of a chunk in registers.
-//   sweep A, chunks left -> right : theta two-pass scan; stores each lane's incoming theta state
-//                                   (20 bytes per 16 elements) to LDS or to a workspace
-//   sweep B, chunks right -> left : theta re-run inside the lane from the stored state, phi two-pass
-//                                   scan with a running carry, epilogue fused into the last phi
-//                                   re-run, G / features staged through LDS for coalesced stores.
+//   sweep A, chunks left -> right : theta scan; stores each lane's incoming theta state
+//                                   (20 bytes per 16 elements) to the workspace
+//   sweep B, chunks right -> left : theta re-run inside the lane from the stored state, phi scan with
+//                                   a running carry, epilogue fused into the last phi re-run,
+//                                   G / features staged through LDS for coalesced stores.
+// First launch: pass 1 by a verified per-lane warm-up (one scan per chunk and direction); second
+// launch: only rows whose verification failed, with pass 1 as a full scan too.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,7 +35,10 @@
 
 namespace {
 
-constexpr int T = 256;             // threads per workgroup
+#ifndef BK_T
+#define BK_T 256
+#endif
+constexpr int T = BK_T;            // threads per workgroup
 #ifndef BK_E
 #define BK_E 16
 #endif
@@ -43,10 +48,6 @@ constexpr int WAVES = T / 64;
 #ifndef BK_WAVES_PER_SIMD
 #define BK_WAVES_PER_SIMD 2
 #endif
-#ifndef BK_LDS_STATE_CHUNKS
-#define BK_LDS_STATE_CHUNKS 8
-#endif
-constexpr int LDS_STATE_CHUNKS = BK_LDS_STATE_CHUNKS;  // rows of up to this many chunks keep the lane states in LDS
 constexpr long MAX_N = 1L << 24;
 constexpr float LN2_HALF = 0.34657359027997264f;  // 0.5 * ln 2
 constexpr float LOG2E = 1.4426950408889634f;
@@ -74,22 +75,31 @@ __device__ __forceinline__ float2 rstep(float2 al, float ka, float2 x, float2 p)
 }
 __device__ __forceinline__ float amax2(float2 p) { return fmaxf(fabsf(p.x), fabsf(p.y)); }
 __device__ __forceinline__ float2 ld2(float2 p, int e) { return make_float2(ldexpf(p.x, e), ldexpf(p.y, e)); }
+// 2^-de as a float, for |de| <= 126 (mantissas are renormalised often enough that |de| stays far below that;
+// the clamp only protects the bit trick against garbage exponents of non-finite states)
+__device__ __forceinline__ float pow2_neg(int de) {
+  const int c = min(max(de, -126), 126);
+  return __int_as_float((127 - c) << 23);
+}
+__device__ __forceinline__ float2 sc2(float2 p, float s) { return make_float2(p.x * s, p.y * s); }
 // exponent e with m * 2^-e in [0.5,1); 0 for m == 0, inf, nan
 __device__ __forceinline__ int expo(float m) { return __builtin_amdgcn_frexp_expf(m); }
 __device__ __forceinline__ float log2_norm2(float2 p) { return __builtin_amdgcn_logf(fmaf(p.x, p.x, p.y * p.y)); }
 
 __device__ __forceinline__ void vnorm(Vec &v) {
   const int de = expo(fmaxf(amax2(v.x0), amax2(v.x1)));
-  v.x0 = ld2(v.x0, -de);
-  v.x1 = ld2(v.x1, -de);
+  const float s = pow2_neg(de);
+  v.x0 = sc2(v.x0, s);
+  v.x1 = sc2(v.x1, s);
   v.e += de;
 }
 __device__ __forceinline__ void mnorm(Mat &m) {
   const int de = expo(fmaxf(fmaxf(amax2(m.a), amax2(m.b)), fmaxf(amax2(m.c), amax2(m.d))));
-  m.a = ld2(m.a, -de);
-  m.b = ld2(m.b, -de);
-  m.c = ld2(m.c, -de);
-  m.d = ld2(m.d, -de);
+  const float s = pow2_neg(de);
+  m.a = sc2(m.a, s);
+  m.b = sc2(m.b, s);
+  m.c = sc2(m.c, s);
+  m.d = sc2(m.d, s);
   m.e += de;
 }
 // p * q (p applied after q)
@@ -204,6 +214,13 @@ struct Shared {
   } u;
   Mat tot[2][WAVES];          // per-wave aggregates, double-buffered across scans
   Vec carry[2][2];            // running chunk carries (pass 1 / pass 2), double-buffered across chunks
+  Vec warm[WAVES];            // last lane's warm-up state of each wave (fast path hand-off to the next wave)
+};
+
+// Which LDS slots the next scan uses: per-wave totals alternate every scan, each carry alternates every use.
+struct ScanCtx {
+  int nscan;
+  int cpar[2];
 };
 
 __device__ __forceinline__ int pad32(int idx) { return idx + (idx >> 5); }
@@ -260,8 +277,9 @@ __device__ __forceinline__ Mat wall_and_aggregate(const float2 (&al)[E], const f
       agg_step(A, al[ei], kk);
       if ((j & 1) == 1) {
         const int de = expo(fmaxf(amax2(x.x0), amax2(x.x1)));
-        x.x0 = ld2(x.x0, -de);
-        x.x1 = ld2(x.x1, -de);
+        const float s = pow2_neg(de);
+        x.x0 = sc2(x.x0, s);
+        x.x1 = sc2(x.x1, s);
         l1 -= 2.0f * (float)de;
       }
       l0 = log2_norm2(x.x0);
@@ -269,6 +287,60 @@ __device__ __forceinline__ Mat wall_and_aggregate(const float2 (&al)[E], const f
     if ((j & 3) == 3) mnorm(A);
   }
   return A;
+}
+
+// ---- fast path for pass 1 -----------------------------------------------------------------------------------
+// The wall factor needs only the RATIO of consecutive terms, to about 1e-3.  Wherever the ratio map of the
+// recurrence is contracting (every well-conditioned input), a lane's outgoing ratio forgets its incoming one
+// within a few steps: each lane runs the linear recurrence over its own 16 elements from the start vector and
+// hands the result to the next lane as that lane's pass-1 state; no pass-1 product and no pass-1 scan.
+// The estimate is checked afterwards against the exact pass-2 state (ratio_differs); a row with any mismatch is
+// recomputed by the two-scan path in the second launch.
+template <bool REV, bool TAIL, int KO>
+__device__ __forceinline__ Vec warm_run(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask) {
+  Vec x = vec_start();
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const int ei = REV ? E - 1 - j : j;
+    if (!TAIL || ((vmask >> ei) & 1u)) {
+      const float2 y = rstep(al[ei], kw[ei + KO], x.x0, x.x1);
+      x.x1 = x.x0;
+      x.x0 = y;
+    }
+    if ((j & 3) == 3) vnorm(x);
+  }
+  return x;
+}
+
+template <bool REV, bool TAIL, int KO>
+__device__ __forceinline__ Vec estimate_incoming(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask,
+                                                 Shared &sh, const ScanCtx &ctx) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const Vec x = warm_run<REV, TAIL, KO>(al, kw, vmask);
+  Vec est;
+  est.x0.x = dpp_f<DPP_WAVE_SHR1, 0xF>(1.0f, x.x0.x);
+  est.x0.y = dpp_f<DPP_WAVE_SHR1, 0xF>(0.0f, x.x0.y);
+  est.x1.x = dpp_f<DPP_WAVE_SHR1, 0xF>(0.0f, x.x1.x);
+  est.x1.y = dpp_f<DPP_WAVE_SHR1, 0xF>(0.0f, x.x1.y);
+  est.e = 0;
+  if (lane == 63) sh.warm[wave] = x;
+  __syncthreads();
+  if (lane == 0) {
+    // first lane of the chunk: the exact running (pass-2) carry; first lane of a later wave: previous wave's last lane
+    est = (wave == 0) ? sh.carry[1][ctx.cpar[1]] : sh.warm[wave > 0 ? wave - 1 : 0];
+  }
+  return est;
+}
+
+// |est.x0/est.x1 - x.x0/x.x1| > tol |x.x0/x.x1| without divisions (false when both second terms are zero)
+__device__ __forceinline__ bool ratio_differs(const Vec &est, const Vec &x) {
+  const float2 c = cmul(est.x0, x.x1);
+  const float2 d = cmul(x.x0, est.x1);
+  const float dx = c.x - d.x, dy = c.y - d.y;
+  const float lhs = fmaf(dx, dx, dy * dy);
+  const float rhs = 4.0e-6f * fmaf(d.x, d.x, d.y * d.y);  // tol = 2e-3
+  return !(lhs <= rhs);
 }
 
 // theta inside one lane from its stored incoming (pass-2) state, two chains in lockstep: a linear one that
@@ -299,10 +371,11 @@ __device__ __forceinline__ void theta_lane(const float2 (&al)[E], const float (&
       l1 = l0;
       if ((j & 1) == 1) {
         const int de = expo(fmaxf(amax2(x.x0), amax2(x.x1)));
-        x.x0 = ld2(x.x0, -de);
-        x.x1 = ld2(x.x1, -de);
-        u0 = ld2(u0, -de);
-        u1 = ld2(u1, -de);
+        const float s = pow2_neg(de);
+        x.x0 = sc2(x.x0, s);
+        x.x1 = sc2(x.x1, s);
+        u0 = sc2(u0, s);
+        u1 = sc2(u1, s);
         x.e += de;
         l1 -= 2.0f * (float)de;
       }
@@ -318,7 +391,7 @@ __device__ __forceinline__ void theta_lane(const float2 (&al)[E], const float (&
 // Wave level: Kogge-Stone over DPP moves (row_shr 1,2,4,8 inside 16-lane rows, then row_bcast 15 / 31 carry the
 // row totals upward); lanes without a source combine with the identity.  Normalised inputs (largest component
 // in [0.5,1)) let two products go by between renormalisations: |entry| <= 2^0.5 -> 2^2 -> 2^5.
-__device__ __forceinline__ Vec block_exclusive(Mat A, int which, Shared &sh, int &scan_count) {
+__device__ __forceinline__ Vec block_exclusive(Mat A, int which, Shared &sh, ScanCtx &ctx) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   A = matmul_raw(A, mat_dpp<DPP_ROW_SHR1, 0xF>(A));
@@ -327,11 +400,12 @@ __device__ __forceinline__ Vec block_exclusive(Mat A, int which, Shared &sh, int
   A = matmul(A, mat_dpp<DPP_ROW_SHR8, 0xF>(A));
   A = matmul_raw(A, mat_dpp<DPP_ROW_BCAST15, 0xA>(A));
   A = matmul(A, mat_dpp<DPP_ROW_BCAST31, 0xC>(A));
-  // each carry is used by every second scan; its two slots alternate so that the new value never
-  // overwrites one that a slower wave may still be reading (a barrier of another scan lies in between)
-  const int buf = scan_count & 1;
-  const int par = (scan_count >> 1) & 1;
-  scan_count++;
+  // a carry's two slots alternate so that the new value never overwrites one that a slower wave may still
+  // be reading (at least one other barrier lies between two uses of the same carry)
+  const int buf = ctx.nscan & 1;
+  const int par = ctx.cpar[which];
+  ctx.nscan++;
+  ctx.cpar[which] ^= 1;
   if (lane == 63) sh.tot[buf][wave] = A;
   const Mat ex = mat_dpp<DPP_WAVE_SHR1, 0xF>(A);  // exclusive prefix inside the wave (identity in lane 0)
   __syncthreads();
@@ -370,19 +444,29 @@ struct RowCfg {
   bool fix_bc;  // replace NaN in b/c by 1 (second launch when he_diag held a NaN)
 };
 
-// Stages chunk at `base` of one row into LDS: a_s[idx] = a[base+idx], k_s[idx] = b[g] c[g] with g = base-1+idx.
+// Stages chunk at `base` of one row into LDS: a_s[idx] = a[base+idx], k_s[idx] = b[g] c[g] with g = base-1+idx
+// (k_s holds CHUNK+1 values; indices outside the row give a = 1, k = 0).
+// FULL: every index idx < CHUNK of all three operands lies inside the row (interior chunks): no bounds logic.
+// Otherwise the loads use clamped (always valid) indices and out-of-row values are replaced afterwards.
 // Returns bit0: NaN seen in a, bit1: NaN seen in b or c.
-template <typename TIn>
+template <typename TIn, bool FULL>
 __device__ __forceinline__ unsigned stage_chunk(const TIn *__restrict__ a, const TIn *__restrict__ b,
                                                 const TIn *__restrict__ c, long base, const RowCfg &cfg, Shared &sh) {
   unsigned seen = 0;
   const int t = threadIdx.x;
+  const TIn *__restrict__ ap = a + base;
+  const int a_hi = (int)min((long)CHUNK, cfg.N - base) - 1;  // last valid idx for a (>= 0)
   {
     float av[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-      const long gi = base + t + j * T;
-      av[j] = (gi < cfg.N) ? to_f32<TIn>(a[gi]) : 1.0f;
+      const int idx = t + j * T;
+      if (FULL) {
+        av[j] = to_f32<TIn>(ap[idx]);
+      } else {
+        const float v = to_f32<TIn>(ap[min(idx, a_hi)]);
+        av[j] = idx <= a_hi ? v : 1.0f;
+      }
     }
 #pragma unroll
     for (int j = 0; j < E; ++j) {
@@ -394,19 +478,38 @@ __device__ __forceinline__ unsigned stage_chunk(const TIn *__restrict__ a, const
       sh.u.in.a_s[pad32(t + j * T)] = v;
     }
   }
-  {
-    float bv[E + 1], cv[E + 1];
+  // b, c: k_s[idx] needs global index g = base - 1 + idx, valid for 0 <= g <= N-2
+  const int k_lo = base == 0 ? 1 : 0;
+  const int k_hi = (int)min((long)CHUNK, cfg.N - 1 - base);  // may be < k_lo (N == 1)
+  if (FULL || k_hi >= k_lo) {
+    const TIn *__restrict__ bp = b + (base - 1);
+    const TIn *__restrict__ cp = c + (base - 1);
+    float bv[E], cv[E];
 #pragma unroll
-    for (int j = 0; j <= E; ++j) {
-      const long g = base - 1 + t + j * T;
-      const bool ok = (j < E || t == 0) && g >= 0 && g < cfg.N - 1;
-      bv[j] = ok ? to_f32<TIn>(b[g]) : 0.0f;
-      cv[j] = ok ? to_f32<TIn>(c[g]) : 0.0f;
+    for (int j = 0; j < E; ++j) {
+      const int idx = t + j * T;
+      if (FULL) {
+        bv[j] = to_f32<TIn>(bp[idx]);
+        cv[j] = to_f32<TIn>(cp[idx]);
+      } else {
+        const int ii = min(max(idx, k_lo), k_hi);
+        const float p = to_f32<TIn>(bp[ii]);
+        const float q = to_f32<TIn>(cp[ii]);
+        const bool ok = idx >= k_lo && idx <= k_hi;
+        bv[j] = ok ? p : 0.0f;
+        cv[j] = ok ? q : 0.0f;
+      }
+    }
+    // the one extra value k_s[CHUNK] (k of the chunk's last element), loaded by thread 0
+    float be = 0.0f, ce = 0.0f;
+    if (t == 0 && k_hi >= CHUNK) {
+      be = to_f32<TIn>(bp[CHUNK]);
+      ce = to_f32<TIn>(cp[CHUNK]);
     }
 #pragma unroll
     for (int j = 0; j <= E; ++j) {
       if (j < E || t == 0) {
-        float p = bv[j], q = cv[j];
+        float p = j < E ? bv[j] : be, q = j < E ? cv[j] : ce;
         if (!cfg.raw) {
           p = clamp_keep_nan(p, 10.0f);
           q = clamp_keep_nan(q, 10.0f);
@@ -416,6 +519,10 @@ __device__ __forceinline__ unsigned stage_chunk(const TIn *__restrict__ a, const
         sh.u.in.k_s[pad32(t + j * T)] = p * q;
       }
     }
+  } else {
+#pragma unroll
+    for (int j = 0; j <= E; ++j)
+      if (j < E || t == 0) sh.u.in.k_s[pad32(t + j * T)] = 0.0f;
   }
   return seen;
 }
@@ -446,7 +553,6 @@ __device__ __forceinline__ void fetch_elems(const Shared &sh, long base, int seg
 
 // ---- the forward kernel -------------------------------------------------------------------------------------
 // lane-state storage: 5 floats per (chunk, thread), laid out [chunk][field][thread]
-template <bool LDS_STATE>
 __device__ __forceinline__ void put_state(float *st, int ch, int seg, const Vec &x) {
   float *p = st + (long)ch * 5 * T + seg;
   p[0] = x.x0.x;
@@ -455,7 +561,6 @@ __device__ __forceinline__ void put_state(float *st, int ch, int seg, const Vec 
   p[3 * T] = x.x1.y;
   p[4 * T] = __int_as_float(x.e);
 }
-template <bool LDS_STATE>
 __device__ __forceinline__ Vec get_state(const float *st, int ch, int seg) {
   const float *p = st + (long)ch * 5 * T + seg;
   Vec x;
@@ -467,15 +572,30 @@ __device__ __forceinline__ Vec get_state(const float *st, int ch, int seg) {
   return x;
 }
 
-template <bool TAIL, int KO_PHI>
+// Pass 1 + pass 2 of one chunk in one direction: fills k2 (wall-corrected k per element) and returns the lane's
+// exact incoming pass-2 state.  FAST: pass 1 by the verified warm-up estimate instead of a product + scan.
+template <bool FAST, bool REV, bool TAIL, int KO>
+__device__ __forceinline__ Vec two_pass(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask,
+                                        float (&k2)[E], Shared &sh, ScanCtx &ctx, bool &bad) {
+  Vec est;
+  if (FAST) {
+    est = estimate_incoming<REV, TAIL, KO>(al, kw, vmask, sh, ctx);
+  } else {
+    const Mat A1 = lane_aggregate<REV, TAIL, KO>(al, kw, vmask);
+    est = block_exclusive(A1, 0, sh, ctx);
+  }
+  const Mat A2 = wall_and_aggregate<REV, TAIL, KO>(al, kw, vmask, est, k2);
+  const Vec x = block_exclusive(A2, 1, sh, ctx);
+  if (FAST) bad |= ratio_differs(est, x);
+  return x;
+}
+
+template <bool FAST, bool TAIL, int KO_PHI>
 __device__ __forceinline__ void sweepB_chunk(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask,
-                                             const Vec &xt, float2 inv_det, int e_det, Shared &sh, int &scan_count,
-                                             int seg) {
-  Mat A = lane_aggregate<true, TAIL, KO_PHI>(al, kw, vmask);
-  Vec x = block_exclusive(A, 0, sh, scan_count);
+                                             const Vec &xt, float2 inv_det, int e_det, Shared &sh, ScanCtx &ctx,
+                                             int seg, bool &bad) {
   float k2[E];
-  A = wall_and_aggregate<true, TAIL, KO_PHI>(al, kw, vmask, x, k2);
-  x = block_exclusive(A, 1, sh, scan_count);
+  Vec x = two_pass<FAST, true, TAIL, KO_PHI>(al, kw, vmask, k2, sh, ctx, bad);
   // theta of the lane's elements into the lane's slots of the output tile.  (All reads of the staged inputs
   // happened before the scans' barriers, so the tile may overwrite them; each slot is touched by this thread only.)
   float2 *slot = &sh.u.out_s[pad16(seg * E)];
@@ -496,7 +616,8 @@ __device__ __forceinline__ void sweepB_chunk(const float2 (&al)[E], const float 
     const float m2 = fmaf(g.x, g.x, g.y * g.y);
     const float clip = (m2 > 2500.0f) ? 50.0f * __builtin_amdgcn_rsqf(m2) : 1.0f;
     g = make_float2(g.x * clip, g.y * clip);
-    if (!(fabsf(g.x) <= 3.0e38f) || !(fabsf(g.y) <= 3.0e38f)) g = make_float2(0.f, 0.f);
+    // a finite g has |g| <= e^4 here, so g is non-finite exactly when |g|^2 is not an ordinary number
+    if (!(m2 <= 3.0e38f)) g = make_float2(0.f, 0.f);
     slot[ei] = g;
     if (!TAIL || ((vmask >> ei) & 1u)) {
       const float2 y = rstep(al[ei], k2[ei], x.x0, x.x1);
@@ -520,39 +641,49 @@ __device__ __forceinline__ float2 fix_tiny(float2 g) {
   return g;
 }
 
-template <typename TIn, bool LDS_STATE, bool PHI_EXACT>
-__global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_,
-                                                       long ldb, const TIn *__restrict__ c_, long ldc,
-                                                       const float *__restrict__ z_dev, float z_re, float z_im, long N,
-                                                       float2 *__restrict__ G_, float2 *__restrict__ F_,
-                                                       float *__restrict__ ws, int *state, int call_id, int fixup,
-                                                       unsigned flags) {
+// Workspace layout: B ints (per-row verdict of the fast path), padded to 256 bytes, then the lane states.
+__host__ __device__ inline size_t rowflag_bytes(long B) { return (((size_t)B * sizeof(int)) + 255) & ~(size_t)255; }
+
+// FAST = first launch (fast pass 1, verified); !FAST = second launch: rows whose verification failed, or every row
+// when he_diag held a NaN and b/c held a NaN (then with b/c NaNs replaced by 1, bk_core.py:260-264).
+template <typename TIn, bool PHI_EXACT, bool FAST>
+__global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
+    const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
+    const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, float2 *__restrict__ G_,
+    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, int second, unsigned flags) {
   __shared__ Shared sh;
-  __shared__ float lane_state_lds[(LDS_STATE && LDS_STATE_CHUNKS > 0) ? LDS_STATE_CHUNKS * 5 * T : 1];
-  if (fixup) {
-    // second launch: only when this call saw a NaN in he_diag AND a NaN in b/c
+  const long row = blockIdx.x;
+  int *rowflag = reinterpret_cast<int *>(ws);
+  bool fix_bc = false;
+  if (second) {
     const int sa = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int sb = __hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (sa != call_id || sb != call_id) return;
+    const int sc = __hip_atomic_load(&state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fix_bc = (sa == call_id && sb == call_id) && !(flags & BKCORE_FLAG_RAW);
+    const bool redo_row = (sc == call_id) && rowflag[row] != 0;
+    if (!fix_bc && !redo_row) return;
   }
-  const long row = blockIdx.x;
   const TIn *a = a_ + row * lda;
   const TIn *b = b_ + row * ldb;
   const TIn *c = c_ + row * ldc;
   float2 *G = G_ + row * N;
   float2 *F = F_ ? F_ + row * N : nullptr;
   const int nch = (int)((N + CHUNK - 1) / CHUNK);
-  float *st = LDS_STATE ? lane_state_lds : ws + row * (long)nch * 5 * T;
+  float *st = reinterpret_cast<float *>(ws + rowflag_bytes(B)) + row * (long)nch * 5 * T;
 
   RowCfg cfg;
   cfg.z = z_dev ? make_float2(z_dev[0], z_dev[1]) : make_float2(z_re, z_im);
   cfg.N = N;
   cfg.raw = (flags & BKCORE_FLAG_RAW) != 0;
-  cfg.fix_bc = fixup != 0;
+  cfg.fix_bc = fix_bc;
 
   const int t = threadIdx.x;
-  int scan_count = 0;
+  ScanCtx ctx;
+  ctx.nscan = 0;
+  ctx.cpar[0] = 0;
+  ctx.cpar[1] = 0;
   unsigned seen = 0;
+  bool bad = false;
   float2 al[E];
   float kw[E + 1];
   unsigned vmask;
@@ -565,27 +696,24 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(const 
   for (int ch = 0; ch < nch; ++ch) {
     const long base = (long)ch * CHUNK;
     __syncthreads();  // previous chunk's LDS reads done
-    seen |= stage_chunk<TIn>(a, b, c, base, cfg, sh);
+    const bool full = base > 0 && base + CHUNK <= N - 1;
+    if (full)
+      seen |= stage_chunk<TIn, true>(a, b, c, base, cfg, sh);
+    else
+      seen |= stage_chunk<TIn, false>(a, b, c, base, cfg, sh);
     __syncthreads();
     fetch_elems(sh, base, t, cfg, al, kw, vmask);
     float k2[E];
     Vec x;
-    if (base + CHUNK <= N) {
-      Mat A = lane_aggregate<false, false, 0>(al, kw, vmask);
-      x = block_exclusive(A, 0, sh, scan_count);
-      A = wall_and_aggregate<false, false, 0>(al, kw, vmask, x, k2);
-      x = block_exclusive(A, 1, sh, scan_count);
-    } else {
-      Mat A = lane_aggregate<false, true, 0>(al, kw, vmask);
-      x = block_exclusive(A, 0, sh, scan_count);
-      A = wall_and_aggregate<false, true, 0>(al, kw, vmask, x, k2);
-      x = block_exclusive(A, 1, sh, scan_count);
-    }
-    put_state<LDS_STATE>(st, ch, t, x);
+    if (base + CHUNK <= N)
+      x = two_pass<FAST, false, false, 0>(al, kw, vmask, k2, sh, ctx, bad);
+    else
+      x = two_pass<FAST, false, true, 0>(al, kw, vmask, k2, sh, ctx, bad);
+    put_state(st, ch, t, x);
   }
   // theta_N = first component of the pass-2 state after the last element
   __syncthreads();
-  const Vec cdet = sh.carry[1][(scan_count >> 1) & 1];
+  const Vec cdet = sh.carry[1][ctx.cpar[1]];
   const float2 dm = cdet.x0;
   const int e_det = cdet.e;
   const float dn = fmaf(dm.x, dm.x, dm.y * dm.y);
@@ -594,36 +722,60 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(const 
 
   // ---- sweep B: phi with running carry, theta from the stored lane states, epilogue, stores
   if (t == 0) {
-    sh.carry[0][(scan_count >> 1) & 1] = vec_start();
-    sh.carry[1][(scan_count >> 1) & 1] = vec_start();
+    sh.carry[0][ctx.cpar[0]] = vec_start();
+    sh.carry[1][ctx.cpar[1]] = vec_start();
   }
   constexpr int KO_PHI = PHI_EXACT ? 1 : 0;
   for (int ch = nch - 1; ch >= 0; --ch) {
     const long base = (long)ch * CHUNK;
     __syncthreads();  // previous chunk's out_s reads done (and lane states visible)
-    stage_chunk<TIn>(a, b, c, base, cfg, sh);
+    const bool full = base > 0 && base + CHUNK <= N - 1;
+    if (full)
+      stage_chunk<TIn, true>(a, b, c, base, cfg, sh);
+    else
+      stage_chunk<TIn, false>(a, b, c, base, cfg, sh);
     __syncthreads();
     const int seg = T - 1 - t;  // descending segments over ascending threads: phi's processing order
     fetch_elems(sh, base, seg, cfg, al, kw, vmask);
-    const Vec xt = get_state<LDS_STATE>(st, ch, seg);
+    const Vec xt = get_state(st, ch, seg);
     if (base + CHUNK <= N)
-      sweepB_chunk<false, KO_PHI>(al, kw, vmask, xt, inv_det, e_det, sh, scan_count, seg);
+      sweepB_chunk<FAST, false, KO_PHI>(al, kw, vmask, xt, inv_det, e_det, sh, ctx, seg, bad);
     else
-      sweepB_chunk<true, KO_PHI>(al, kw, vmask, xt, inv_det, e_det, sh, scan_count, seg);
+      sweepB_chunk<FAST, true, KO_PHI>(al, kw, vmask, xt, inv_det, e_det, sh, ctx, seg, bad);
     __syncthreads();
     // coalesced stores of G and features (same numbers, bk_core.py:296-298)
+    float2 *__restrict__ Gc = G + base;
+    float2 *__restrict__ Fc = F ? F + base : nullptr;
+    if (base + CHUNK <= N) {
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
-      const int idx = t + j * T;
-      const long gi = base + idx;
-      if (gi < N) {
+      for (int j = 0; j < E; ++j) {
+        const int idx = t + j * T;
         const float2 g = fix_tiny(sh.u.out_s[pad16(idx)]);
-        G[gi] = g;
-        if (F) F[gi] = g;
+        Gc[idx] = g;
+        if (Fc) Fc[idx] = g;
+      }
+    } else {
+      const int n_here = (int)(N - base);
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        const int idx = t + j * T;
+        if (idx < n_here) {
+          const float2 g = fix_tiny(sh.u.out_s[pad16(idx)]);
+          Gc[idx] = g;
+          if (Fc) Fc[idx] = g;
+        }
       }
     }
   }
-  if (state && !fixup && seen) {
+  if (FAST) {
+    // verdict of the fast path for this row; the second launch recomputes the rows that failed
+    const int any_bad = __syncthreads_or(bad ? 1 : 0);
+    if (t == 0) {
+      rowflag[row] = any_bad;
+      if (any_bad) __hip_atomic_store(&state[2], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (state && !second && seen) {
     if (seen & 1u) __hip_atomic_store(&state[0], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (seen & 2u) __hip_atomic_store(&state[1], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -701,7 +853,7 @@ int g_call_counter = 0;
 
 inline int chunks_of(int64_t N) { return (int)((N + CHUNK - 1) / CHUNK); }
 
-template <typename TIn, bool LDS_STATE, bool PHI_EXACT>
+template <typename TIn, bool PHI_EXACT>
 int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
                     const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
                     void *ws, void *state, unsigned flags, hipStream_t stream) {
@@ -713,17 +865,33 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
       call_id = 1;
     }
   }
-  const int launches = (state && !(flags & BKCORE_FLAG_RAW)) ? 2 : 1;
-  for (int fixup = 0; fixup < launches; ++fixup) {
-    hipLaunchKernelGGL((bk_forward_kernel<TIn, LDS_STATE, PHI_EXACT>), dim3((unsigned)B), dim3(T), 0, stream,
-                       (const TIn *)a, (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re,
-                       z_im, (long)N, (float2 *)G, (float2 *)features, (float *)ws, (int *)state, call_id, fixup, flags);
+#define BK_LAUNCH(FASTV, SECOND)                                                                                     \
+  hipLaunchKernelGGL((bk_forward_kernel<TIn, PHI_EXACT, FASTV>), dim3((unsigned)B), dim3(T), 0, stream,              \
+                     (const TIn *)a, (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re,   \
+                     z_im, (long)B, (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id,     \
+                     SECOND, flags)
+  if (state) {
+    // fast first launch, then the (normally empty) second launch for rows that need the two-scan path
+    BK_LAUNCH(true, 0);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess) {
+      BK_LAUNCH(false, 1);
+      err = hipGetLastError();
+    }
+    if (err != hipSuccess) {
+      g_last_hip_error = (int)err;
+      return BKCORE_ELAUNCH;
+    }
+  } else {
+    // no persistent state block: nothing can carry a verdict to a second launch, so take the two-scan path at once
+    BK_LAUNCH(false, 0);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
       g_last_hip_error = (int)err;
       return BKCORE_ELAUNCH;
     }
   }
+#undef BK_LAUNCH
   return BKCORE_OK;
 }
 
@@ -731,17 +899,9 @@ template <typename TIn>
 int launch_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
                    const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
                    void *ws, void *state, unsigned flags, hipStream_t s) {
-  const bool lds = chunks_of(N) <= LDS_STATE_CHUNKS;
-  const bool ex = (flags & BKCORE_FLAG_PHI_EXACT) != 0;
-#define BK_GO(L, X) \
-  return launch_forward2<TIn, L, X>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state, flags, s)
-  if (lds) {
-    if (ex) BK_GO(true, true);
-    BK_GO(true, false);
-  }
-  if (ex) BK_GO(false, true);
-  BK_GO(false, false);
-#undef BK_GO
+  if (flags & BKCORE_FLAG_PHI_EXACT)
+    return launch_forward2<TIn, true>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state, flags, s);
+  return launch_forward2<TIn, false>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state, flags, s);
 }
 
 }  // namespace
@@ -750,9 +910,7 @@ extern "C" {
 
 size_t bkcore_workspace_bytes(int64_t B, int64_t N) {
   if (B <= 0 || N <= 0) return 0;
-  const int nch = chunks_of(N);
-  if (nch <= LDS_STATE_CHUNKS) return 0;
-  return (size_t)B * (size_t)nch * 5 * T * sizeof(float);
+  return rowflag_bytes(B) + (size_t)B * (size_t)chunks_of(N) * 5 * T * sizeof(float);
 }
 
 int bkcore_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc, int in_dtype,
@@ -769,12 +927,14 @@ int bkcore_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const
   switch (in_dtype) {
     case BKCORE_F32:
       return launch_forward<float>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, workspace, state, flags, s);
+#ifndef BK_DEV_F32_ONLY
     case BKCORE_BF16:
       return launch_forward<uint16_t>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, workspace, state, flags, s);
     case BKCORE_F16:
       return launch_forward<_Float16>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, workspace, state, flags, s);
     case BKCORE_F64:
       return launch_forward<double>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, workspace, state, flags, s);
+#endif
     default:
       return BKCORE_EINVAL;
   }
@@ -810,7 +970,7 @@ int bkcore_backward_ref(const float *G, const float *grad_features, const float 
 
 int64_t bkcore_max_seq_len(void) { return (int64_t)MAX_N; }
 int bkcore_last_hip_error(void) { return g_last_hip_error; }
-int bkcore_abi_version(void) { return 2; }
+int bkcore_abi_version(void) { return 3; }
 
 const char *bkcore_error_string(int code) {
   switch (code) {
