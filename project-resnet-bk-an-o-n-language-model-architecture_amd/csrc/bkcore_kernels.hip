@@ -75,12 +75,9 @@ __device__ __forceinline__ float2 rstep(float2 al, float ka, float2 x, float2 p)
 }
 __device__ __forceinline__ float amax2(float2 p) { return fmaxf(fabsf(p.x), fabsf(p.y)); }
 __device__ __forceinline__ float2 ld2(float2 p, int e) { return make_float2(ldexpf(p.x, e), ldexpf(p.y, e)); }
-// 2^-de as a float, for |de| <= 126 (mantissas are renormalised often enough that |de| stays far below that;
-// the clamp only protects the bit trick against garbage exponents of non-finite states)
-__device__ __forceinline__ float pow2_neg(int de) {
-  const int c = min(max(de, -126), 126);
-  return __int_as_float((127 - c) << 23);
-}
+// 2^-de as a float, exact for -126 <= de <= 126.  de comes from v_frexp_exp of a mantissa that is renormalised
+// every few steps, so it only leaves that range once a state has already overflowed to inf/NaN.
+__device__ __forceinline__ float pow2_neg(int de) { return __int_as_float((127 - de) << 23); }
 __device__ __forceinline__ float2 sc2(float2 p, float s) { return make_float2(p.x * s, p.y * s); }
 // exponent e with m * 2^-e in [0.5,1); 0 for m == 0, inf, nan
 __device__ __forceinline__ int expo(float m) { return __builtin_amdgcn_frexp_expf(m); }
@@ -188,7 +185,7 @@ constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHR1 = 
 // (a ratio of consecutive terms beyond e^22 is below float32 resolution of the recurrence).  A non-finite d
 // (an exactly zero term, e.g. the start vector's theta_{-1} = 0) gives 1.
 __device__ __forceinline__ float wall_exponent(float d) {
-  const float dc = fminf(fmaxf(d, -WALL_DMAX), WALL_DMAX);
+  const float dc = __builtin_amdgcn_fmed3f(d, -WALL_DMAX, WALL_DMAX);  // a NaN d comes out as a bound, i.e. finite
   const float u = dc * (1.0f / 88.0f);
   const float s = u * u;
   float p = fmaf(s, 1382.0f / 155925.0f, -62.0f / 2835.0f);
@@ -468,14 +465,22 @@ __device__ __forceinline__ unsigned stage_chunk(const TIn *__restrict__ a, const
         av[j] = idx <= a_hi ? v : 1.0f;
       }
     }
+    float probe = 0.0f;  // NaN iff some value is NaN (or +inf and -inf meet: handled exactly below as well)
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
-      float v = av[j];
-      if (!cfg.raw) {
-        v = clamp_keep_nan(v, 100.0f);
+    for (int j = 0; j < E; ++j) probe += av[j];
+    if (cfg.raw) {
+#pragma unroll
+      for (int j = 0; j < E; ++j) sh.u.in.a_s[pad32(t + j * T)] = av[j];
+    } else if (__builtin_expect(!__any(probe != probe), 1)) {
+#pragma unroll
+      for (int j = 0; j < E; ++j) sh.u.in.a_s[pad32(t + j * T)] = __builtin_amdgcn_fmed3f(av[j], -100.0f, 100.0f);
+    } else {
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        float v = clamp_keep_nan(av[j], 100.0f);
         if (v != v) { v = 0.0f; seen |= 1u; }
+        sh.u.in.a_s[pad32(t + j * T)] = v;
       }
-      sh.u.in.a_s[pad32(t + j * T)] = v;
     }
   }
   // b, c: k_s[idx] needs global index g = base - 1 + idx, valid for 0 <= g <= N-2
@@ -506,17 +511,29 @@ __device__ __forceinline__ unsigned stage_chunk(const TIn *__restrict__ a, const
       be = to_f32<TIn>(bp[CHUNK]);
       ce = to_f32<TIn>(cp[CHUNK]);
     }
+    float probe = be + ce;
 #pragma unroll
-    for (int j = 0; j <= E; ++j) {
-      if (j < E || t == 0) {
-        float p = j < E ? bv[j] : be, q = j < E ? cv[j] : ce;
-        if (!cfg.raw) {
-          p = clamp_keep_nan(p, 10.0f);
-          q = clamp_keep_nan(q, 10.0f);
+    for (int j = 0; j < E; ++j) probe += bv[j] + cv[j];
+    if (cfg.raw) {
+#pragma unroll
+      for (int j = 0; j < E; ++j) sh.u.in.k_s[pad32(t + j * T)] = bv[j] * cv[j];
+      if (t == 0) sh.u.in.k_s[pad32(CHUNK)] = be * ce;
+    } else if (__builtin_expect(!__any(probe != probe), 1)) {
+#pragma unroll
+      for (int j = 0; j < E; ++j)
+        sh.u.in.k_s[pad32(t + j * T)] =
+            __builtin_amdgcn_fmed3f(bv[j], -10.0f, 10.0f) * __builtin_amdgcn_fmed3f(cv[j], -10.0f, 10.0f);
+      if (t == 0)
+        sh.u.in.k_s[pad32(CHUNK)] = __builtin_amdgcn_fmed3f(be, -10.0f, 10.0f) * __builtin_amdgcn_fmed3f(ce, -10.0f, 10.0f);
+    } else {
+#pragma unroll
+      for (int j = 0; j <= E; ++j) {
+        if (j < E || t == 0) {
+          float p = clamp_keep_nan(j < E ? bv[j] : be, 10.0f), q = clamp_keep_nan(j < E ? cv[j] : ce, 10.0f);
           if (p != p) { seen |= 2u; if (cfg.fix_bc) p = 1.0f; }
           if (q != q) { seen |= 2u; if (cfg.fix_bc) q = 1.0f; }
+          sh.u.in.k_s[pad32(t + j * T)] = p * q;
         }
-        sh.u.in.k_s[pad32(t + j * T)] = p * q;
       }
     }
   } else {
@@ -538,16 +555,24 @@ __device__ __forceinline__ void fetch_elems(const Shared &sh, long base, int seg
   const long first = base + (long)seg * E;
   const long left = cfg.N - first;
   vmask = left >= E ? ((1u << E) - 1u) : (left <= 0 ? 0u : ((1u << (int)left) - 1u));
+  const float xi = -cfg.z.y;
+  if (xi * xi >= 1e-24f) {
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const float av = sh.u.in.a_s[pad32(seg * E + e)];
-    const float xr = av - cfg.z.x;
-    const float xi = -cfg.z.y;
-    const float n = fmaf(xr, xr, xi * xi);
-    float f = fmaf(1e-3f, __builtin_amdgcn_rsqf(n), 1.0f);
-    float add = 0.0f;
-    if (!(n >= 1e-24f)) { f = 1.0f; add = 1e-3f; }  // |x| < 1e-12: direction taken as 1 (bk_core.py:89-90)
-    al[e] = make_float2(fmaf(xr, f, add), xi * f);
+    for (int e = 0; e < E; ++e) {
+      const float xr = sh.u.in.a_s[pad32(seg * E + e)] - cfg.z.x;
+      const float f = fmaf(1e-3f, __builtin_amdgcn_rsqf(fmaf(xr, xr, xi * xi)), 1.0f);
+      al[e] = make_float2(xr * f, xi * f);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float xr = sh.u.in.a_s[pad32(seg * E + e)] - cfg.z.x;
+      const float n = fmaf(xr, xr, xi * xi);
+      float f = fmaf(1e-3f, __builtin_amdgcn_rsqf(n), 1.0f);
+      float add = 0.0f;
+      if (!(n >= 1e-24f)) { f = 1.0f; add = 1e-3f; }  // |x| < 1e-12: direction taken as 1 (bk_core.py:89-90)
+      al[e] = make_float2(fmaf(xr, f, add), xi * f);
+    }
   }
 }
 
@@ -610,14 +635,14 @@ __device__ __forceinline__ void sweepB_chunk(const float2 (&al)[E], const float 
     const float n = fmaf(P.x, P.x, P.y * P.y);
     const float L = LN2_HALF * fmaf(2.0f, (float)Ee, __builtin_amdgcn_logf(n));  // ln |G_raw|
     const float sc = ldexpf(__builtin_amdgcn_exp2f(wall_exponent(L) * LOG2E), Ee);
-    // L > 4: exp(88 tanh(L/88)) > 50, the clip makes |G| = 50 (bk_core.py:205-208) whatever the exact magnitude
-    const float f = (L > 4.0f) ? 50.0f * __builtin_amdgcn_rsqf(n) : sc;
-    float2 g = make_float2(P.x * f, P.y * f);
+    float2 g = make_float2(P.x * sc, P.y * sc);
     const float m2 = fmaf(g.x, g.x, g.y * g.y);
-    const float clip = (m2 > 2500.0f) ? 50.0f * __builtin_amdgcn_rsqf(m2) : 1.0f;
-    g = make_float2(g.x * clip, g.y * clip);
-    // a finite g has |g| <= e^4 here, so g is non-finite exactly when |g|^2 is not an ordinary number
-    if (!(m2 <= 3.0e38f)) g = make_float2(0.f, 0.f);
+    if (__builtin_expect(!(m2 <= 2500.0f), 0)) {
+      // |G| > 50: clipped to 50 G/|G| (bk_core.py:205-208; also when 2^Ee overflowed although G_raw is finite:
+      // exp(88 tanh(L/88)) > 50 for every L > 4); anything that is not a number: 0 (bk_core.py:204)
+      const float u = 50.0f * __builtin_amdgcn_rsqf(n);
+      g = (L > 3.9f && L <= 3.0e38f && u <= 3.0e38f) ? make_float2(P.x * u, P.y * u) : make_float2(0.f, 0.f);
+    }
     slot[ei] = g;
     if (!TAIL || ((vmask >> ei) & 1u)) {
       const float2 y = rstep(al[ei], k2[ei], x.x0, x.x1);
