@@ -150,6 +150,14 @@ def main():
         t_bwd = timed(lambda: bkcore.bk_backward_reference(G, gfeat, None, 0.5), reps)
 
     if rank == 0:
+        # HBM traffic of the dominant kernel from the last committed PMC run (profiles/), if it was this workload
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+            if tj.get("rows") == B and tj.get("seq_len") == N:
+                traffic = tj["bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         elems = B * N
         ms = dt / args.steps * 1e3
         value = world * elems / (dt / args.steps)
@@ -171,7 +179,7 @@ def main():
                                    "he_diag=-2+0.5*randn, h0_super=h0_sub=1, z=1j; reference-mode backward",
                        "rows_per_gpu": B, "seq_len": N, "sharding": f"batch rows x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": fwd_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": fwd_bw / HBM_PEAK, "traffic": None,
+                         "frac": fwd_bw / HBM_PEAK, "traffic": traffic,
                          "kernel": "bk_forward_kernel", "bytes_per_elem": FWD_BYTES, "launch_ms": t_fwd * 1e3},
             "fwd_ms": t_fwd * 1e3,
             "bwd_ms": t_bwd * 1e3,
