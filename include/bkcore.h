@@ -94,6 +94,29 @@ size_t bkcore_workspace_bytes(int64_t B, int64_t N);
 int bkcore_backward_ref(const float *G, const float *grad_features, const float *grad_G, float alpha, int64_t n,
                         float *grad_a, void *stream);
 
+/*
+ * Backward, analytic mode: the gradient of L with respect to he_diag, h0_super and h0_sub, where
+ * dL = sum Re(conj(gbar) dG) and gbar = grad_features[...,0] + i grad_features[...,1] (+ grad_G).  It is the
+ * derivative of what bkcore_forward computes -- regularisation, both soft clamps, the |G| <= 50 clip and the chosen
+ * phi index convention included -- i.e. what torch.autograd gives through the reference's sequential forward
+ * (src/models/bk_core.py:27-210) evaluated in float64.  No counterpart in the reference, whose backward is the
+ * heuristic blend above and returns None for h0_super / h0_sub (src/models/bk_core.py:384-385).
+ *
+ * a, b, c: float32, ALREADY clamped / NaN-sanitised as BKCoreFunction.forward does (src/models/bk_core.py:256-264; the
+ *    caller zeroes the gradient where the clamp was active); leading dimensions as in bkcore_forward.
+ * grad_features: B*N*2 floats or NULL; grad_G: B*N complex64 or NULL.
+ * grad_a: B*N floats.  grad_b, grad_c: B*(N-1) floats each, or both NULL.
+ * flags: BKCORE_FLAG_PHI_EXACT or 0, as given to the forward.
+ * workspace: at least bkcore_backward_analytic_workspace_bytes(B, N) bytes (the forward is re-run inside this call
+ *    to obtain the theta / phi ratios; nothing from the caller's forward is needed); state: as in bkcore_forward.
+ */
+int bkcore_backward_analytic(const float *a, int64_t lda, const float *b, int64_t ldb, const float *c, int64_t ldc,
+                             const float *z_dev, float z_re, float z_im, int64_t B, int64_t N,
+                             const float *grad_features, const float *grad_G, float *grad_a, float *grad_b,
+                             float *grad_c, void *workspace, size_t workspace_bytes, void *state, unsigned flags,
+                             void *stream);
+size_t bkcore_backward_analytic_workspace_bytes(int64_t B, int64_t N);
+
 /* Largest N bkcore_forward accepts. */
 int64_t bkcore_max_seq_len(void);
 /* HIP error code of the last failed launch on this thread (0 if none). */

@@ -1,6 +1,7 @@
 """MI355X-native BK-Core: host-side mirror of the reference operator API (src/models/bk_core.py)."""
 from .bk_core import (BKCoreFunction, get_tridiagonal_inverse_diagonal, vmapped_get_diag, set_triton_mode,
-                      get_triton_mode, bk_forward, bk_backward_reference)
+                      get_triton_mode, bk_forward, bk_backward_reference, bk_backward_analytic,
+                      sanitise_inputs)
 
 __all__ = ["BKCoreFunction", "get_tridiagonal_inverse_diagonal", "vmapped_get_diag", "set_triton_mode",
-           "get_triton_mode", "bk_forward", "bk_backward_reference"]
+           "get_triton_mode", "bk_forward", "bk_backward_reference", "bk_backward_analytic", "sanitise_inputs"]

@@ -157,6 +157,71 @@ def bk_backward_reference(G, grad_features, grad_G, alpha: float):
     return out
 
 
+def sanitise_inputs(he_diag, h0_super, h0_sub):
+    """float32 copies of the operands after the operator's input clamp and conditional NaN replacement
+    (reference bk_core.py:256-264), plus the masks of elements the clamp left untouched (where the gradient
+    passes).  Device-side only: no host synchronisation."""
+    a = he_diag.float()
+    b = h0_super.float()
+    c = h0_sub.float()
+    pa = (a.abs() <= 100.0)
+    pb = (b.abs() <= 10.0)
+    pc = (c.abs() <= 10.0)
+    bad = torch.isnan(a).any()
+    a = torch.clamp(a, -100.0, 100.0)
+    b = torch.clamp(b, -10.0, 10.0)
+    c = torch.clamp(c, -10.0, 10.0)
+    a = torch.where(bad, torch.nan_to_num(a, nan=0.0), a)
+    b = torch.where(bad, torch.nan_to_num(b, nan=1.0), b)
+    c = torch.where(bad, torch.nan_to_num(c, nan=1.0), c)
+    return a, b, c, pa, pb, pc
+
+
+def bk_backward_analytic(a, b, c, z, grad_features, grad_G, phi_exact: bool = False, want_bc: bool = True):
+    """Launch the analytic backward.  a (B,N), b/c (B,N-1): float32, already sanitised.
+    Returns (grad_a, grad_b|None, grad_c|None), float32."""
+    L = _lib.load()
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or c.dtype != torch.float32:
+        raise TypeError("bkcore: bk_backward_analytic takes float32 operands")
+    if not a.is_cuda:
+        raise RuntimeError("bkcore: tensors must be on a ROCm device (no CPU path)")
+    B, N = a.shape
+    nb = max(N - 1, 0)
+    ga = torch.empty((B, N), dtype=torch.float32, device=a.device)
+    gb = torch.empty((B, nb), dtype=torch.float32, device=a.device) if want_bc else None
+    gc = torch.empty((B, nb), dtype=torch.float32, device=a.device) if want_bc else None
+    if B == 0 or N == 0:
+        return ga, gb, gc
+    a, pa, lda = _rows(a, N, "a")
+    b, pb, ldb = _rows(b, nb, "b")
+    c, pc, ldc = _rows(c, nb, "c")
+    gf = None
+    if grad_features is not None:
+        gf = grad_features.float().contiguous()
+        if tuple(gf.shape) != (B, N, 2):
+            raise ValueError("bkcore: grad_features must have shape (B, N, 2)")
+    gg = None
+    if grad_G is not None:
+        gg = grad_G.to(torch.complex64).contiguous()
+        if tuple(gg.shape) != (B, N):
+            raise ValueError("bkcore: grad_G must have shape (B, N)")
+    with torch.cuda.device(a.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        zkeep, pz, zre, zim = _prep_z(z, a.device)
+        state = _state_block(a.device, stream)
+        ws_bytes = int(L.bkcore_backward_analytic_workspace_bytes(B, N))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
+        rc = L.bkcore_backward_analytic(pa, lda, pb if nb else None, ldb, pc if nb else None, ldc, pz, zre, zim, B, N,
+                                        gf.data_ptr() if gf is not None else None,
+                                        gg.data_ptr() if gg is not None else None, ga.data_ptr(),
+                                        gb.data_ptr() if gb is not None and nb else None,
+                                        gc.data_ptr() if gc is not None and nb else None, ws.data_ptr(), ws_bytes,
+                                        state.data_ptr(), _lib.FLAG_PHI_EXACT if phi_exact else 0, stream)
+    _lib.check(rc, "bkcore_backward_analytic")
+    del zkeep
+    return ga, gb, gc
+
+
 def vmapped_get_diag(a, b, c, z):
     """Batched diag((T - zI)^-1): (B,N),(B,N-1),(B,N-1),z -> (B,N) complex64.  No input clamps
     (reference bk_core.py:214-216)."""
@@ -175,12 +240,15 @@ class BKCoreFunction(torch.autograd.Function):
     Class attributes kept from the reference: ``GRAD_BLEND`` (read at backward time, bk_core.py:366),
     ``USE_TRITON`` and ``USE_PARALLEL_SCAN`` (accepted, select nothing).
     Added here: ``PHI_K_INDEX`` in {"reference", "exact"} chooses the off-diagonal product used by the
-    phi recurrence (the reference uses k_i, bk_core.py:171).
+    phi recurrence (the reference uses k_i, bk_core.py:171).  ``GRAD_MODE`` in {"reference", "analytic"}, read at
+    forward time: "reference" is the blend of bk_core.py:303-385 (gradient for he_diag only); "analytic" returns
+    the gradient of the resolvent diagonal itself for he_diag, h0_super and h0_sub.
     """
     GRAD_BLEND = 0.5
     USE_TRITON = None
     USE_PARALLEL_SCAN = True
     PHI_K_INDEX = "reference"
+    GRAD_MODE = "reference"
 
     @staticmethod
     def forward(ctx, he_diag, h0_super, h0_sub, z, use_triton=None, use_parallel_scan=None):
@@ -194,15 +262,40 @@ class BKCoreFunction(torch.autograd.Function):
         if he_diag.dim() != 2:
             feats = feats.reshape(*lead, n, 2)
             G = G.reshape(*lead, n)
-        ctx.save_for_backward(G)                       # only G is saved (bk_core.py:293)
         ctx.set_materialize_grads(False)               # an unused output arrives as None, not as a zero tensor
+        ctx.bk_mode = BKCoreFunction.GRAD_MODE
+        if ctx.bk_mode == "analytic":
+            ctx.bk_phi_exact = BKCoreFunction.PHI_K_INDEX == "exact"
+            ctx.bk_z = z.detach() if torch.is_tensor(z) else z
+            ctx.bk_shapes = (he_diag.shape, h0_super.shape, h0_sub.shape)
+            ctx.save_for_backward(he_diag, h0_super, h0_sub)   # the backward re-runs the forward
+        elif ctx.bk_mode == "reference":
+            ctx.save_for_backward(G)                   # only G is saved (bk_core.py:293)
+        else:
+            raise ValueError(f"bkcore: unknown GRAD_MODE {ctx.bk_mode!r}")
         return feats, G
 
     @staticmethod
     def backward(ctx, grad_output_features, grad_G_ii):
-        (G,) = ctx.saved_tensors
         if grad_output_features is None and grad_G_ii is None:
             return None, None, None, None, None, None
+        if ctx.bk_mode == "analytic":
+            a, b, c = ctx.saved_tensors
+            n = a.shape[-1]
+            nb = max(n - 1, 0)
+            rows = a.numel() // max(n, 1)
+            a2, b2, c2, pa, pb, pc = sanitise_inputs(a.reshape(rows, n), b.reshape(rows, nb), c.reshape(rows, nb))
+            gf = grad_output_features.reshape(-1, n, 2) if grad_output_features is not None else None
+            gg = grad_G_ii.reshape(-1, n) if grad_G_ii is not None else None
+            want_bc = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+            ga, gb, gc = bk_backward_analytic(a2, b2, c2, ctx.bk_z, gf, gg,
+                                              phi_exact=ctx.bk_phi_exact, want_bc=want_bc)
+            sa, sb, sc = ctx.bk_shapes
+            ga = (ga * pa).reshape(sa) if ctx.needs_input_grad[0] else None
+            gb_o = (gb * pb).reshape(sb) if ctx.needs_input_grad[1] else None
+            gc_o = (gc * pc).reshape(sc) if ctx.needs_input_grad[2] else None
+            return ga, gb_o, gc_o, None, None, None
+        (G,) = ctx.saved_tensors
         grad = bk_backward_reference(G, grad_output_features, grad_G_ii, BKCoreFunction.GRAD_BLEND)
         return grad, None, None, None, None, None
 

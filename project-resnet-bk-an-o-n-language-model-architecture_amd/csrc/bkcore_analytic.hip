@@ -1,0 +1,411 @@
+// Analytic backward of BK-Core for MI355X (gfx950): the gradient of the operator's own forward with respect to
+// he_diag, h0_super and h0_sub.
+//
+// The reference's backward is a heuristic blend and returns no gradient for the off-diagonals
+// (src/models/bk_core.py:303-385); this file differentiates what the forward (bk_core.py:96-210) computes, written in
+// ratios of consecutive minors:
+//     r_0 = a'_0,          r_i = a'_i - k_{i-1} w(r_{i-1})          (theta_{i+1}/theta_i,  bk_core.py:120-140)
+//     s_{N-1} = a'_{N-1},  s_m = a'_m - kphi_m  w(s_{m+1})          (phi_m/phi_{m+1},      bk_core.py:165-184)
+//     w(r) = exp(g(-ln|r|)) / r,  g(d) = 88 tanh(d/88) - d          (in-recurrence soft clamp, bk_core.py:60-75)
+//     G_raw,j = (1/r_j) prod_{m>j} s_m / r_m ,   G = clip50(G_raw exp(g(ln|G_raw|)))      (bk_core.py:190-208)
+// kphi_m = k_{m-1} in the reference's index convention (bk_core.py:171), k_m with BKCORE_FLAG_PHI_EXACT.
+// With q_j = conj(h_j) G_raw,j (h the cotangent of G_raw) and P_m = sum_{j<=m} q_j,
+//     dL = sum_m Re(-P_m dr_m/r_m) + sum_{m>=1} Re(P_{m-1} ds_m/s_m)
+// and the adjoints of the two ratio recurrences obey first-order recurrences that are linear over the reals
+// (the clamp depends on |r| only, so they are not complex-linear):
+//     lam_m = -P_m    + y - tau(r_m) Re y,   y = k_m    w(r_m) lam_{m+1}/r_{m+1}          right -> left
+//     mu_m  = P_{m-1} + y - tau(s_m) Re y,   y = kphi_{m-1} w(s_m) mu_{m-1}/s_{m-1}      left -> right
+//     tau(r) = tanh^2(ln|r| / 88)
+//     grad_a_m = Re[(lam_m/r_m + mu_m/s_m) D_m],   D_m = d a'_m / d a_m   (regularisation, bk_core.py:78-94)
+//     grad_k_m = -Re[w(r_m) lam_{m+1}/r_{m+1}]  -  Re[w(s_{m'+1}) mu_{m'}/s_{m'}] at kphi_{m'} = k_m
+//     grad_b = c grad_k,  grad_c = b grad_k
+// r, s and G_raw come from a forward launch inside bkcore_backward_analytic (nothing is kept from the caller's
+// forward).  Two kernels, one 256-thread workgroup per row, chunks of 256 x 8 elements; the scans run over affine
+// maps of R^2 (2x2 matrix + vector) with DPP inside a wave and LDS across waves:
+//   bk_adjoint_phi_kernel   : left -> right; P (prefix sum) and mu; writes P, the phi part of grad_a and of grad_k
+//   bk_adjoint_theta_kernel : right -> left; lam; adds the theta parts and writes grad_a, grad_b, grad_c
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bkcore.h"
+#include "bkcore_internal.h"
+
+namespace {
+
+constexpr int T = 256;
+constexpr int EB = 8;
+constexpr int CHUNK = T * EB;
+constexpr int WAVES = T / 64;
+
+__device__ __forceinline__ float2 cmul(float2 p, float2 q) {
+  return make_float2(fmaf(p.x, q.x, -p.y * q.y), fmaf(p.x, q.y, p.y * q.x));
+}
+__device__ __forceinline__ float2 cadd(float2 p, float2 q) { return make_float2(p.x + q.x, p.y + q.y); }
+
+// x -> A x + v on (Re, Im)
+struct Aff {
+  float a00, a01, a10, a11, v0, v1;
+};
+__device__ __forceinline__ Aff aff_identity() { return Aff{1.f, 0.f, 0.f, 1.f, 0.f, 0.f}; }
+__device__ __forceinline__ float2 apply(const Aff &m, float2 x) {
+  return make_float2(fmaf(m.a00, x.x, fmaf(m.a01, x.y, m.v0)), fmaf(m.a10, x.x, fmaf(m.a11, x.y, m.v1)));
+}
+// later after earlier
+__device__ __forceinline__ Aff compose(const Aff &l, const Aff &e) {
+  Aff r;
+  r.a00 = fmaf(l.a00, e.a00, l.a01 * e.a10);
+  r.a01 = fmaf(l.a00, e.a01, l.a01 * e.a11);
+  r.a10 = fmaf(l.a10, e.a00, l.a11 * e.a10);
+  r.a11 = fmaf(l.a10, e.a01, l.a11 * e.a11);
+  r.v0 = fmaf(l.a00, e.v0, fmaf(l.a01, e.v1, l.v0));
+  r.v1 = fmaf(l.a10, e.v0, fmaf(l.a11, e.v1, l.v1));
+  return r;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float src) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Aff aff_dpp(const Aff &m) {  // identity where there is no source lane
+  Aff r;
+  r.a00 = dpp_f<CTRL, ROW_MASK>(1.0f, m.a00);
+  r.a01 = dpp_f<CTRL, ROW_MASK>(0.0f, m.a01);
+  r.a10 = dpp_f<CTRL, ROW_MASK>(0.0f, m.a10);
+  r.a11 = dpp_f<CTRL, ROW_MASK>(1.0f, m.a11);
+  r.v0 = dpp_f<CTRL, ROW_MASK>(0.0f, m.v0);
+  r.v1 = dpp_f<CTRL, ROW_MASK>(0.0f, m.v1);
+  return r;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float2 sum_dpp(float2 v) {
+  return make_float2(dpp_f<CTRL, ROW_MASK>(0.0f, v.x), dpp_f<CTRL, ROW_MASK>(0.0f, v.y));
+}
+
+struct SharedAff {
+  Aff tot[2][WAVES];
+  float2 carry[2];
+};
+struct SharedSum {
+  float2 tot[2][WAVES];
+  float2 carry[2];
+};
+
+// Exclusive scan of the lanes' maps in ascending thread order, applied to the running value kept in LDS (two
+// alternating slots, so one barrier per scan is enough); returns the value entering this lane, advances the carry.
+__device__ __forceinline__ float2 block_exclusive_aff(Aff A, SharedAff &sh, int &nscan) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  A = compose(A, aff_dpp<0x111, 0xF>(A));  // row_shr:1
+  A = compose(A, aff_dpp<0x112, 0xF>(A));  // row_shr:2
+  A = compose(A, aff_dpp<0x114, 0xF>(A));  // row_shr:4
+  A = compose(A, aff_dpp<0x118, 0xF>(A));  // row_shr:8
+  A = compose(A, aff_dpp<0x142, 0xA>(A));  // row_bcast:15 into rows 1, 3
+  A = compose(A, aff_dpp<0x143, 0xC>(A));  // row_bcast:31 into rows 2, 3
+  const int buf = nscan & 1;
+  nscan++;
+  if (lane == 63) sh.tot[buf][wave] = A;
+  const Aff ex = aff_dpp<0x138, 0xF>(A);  // wave_shr:1
+  __syncthreads();
+  float2 x = sh.carry[buf];
+  float2 xin = x;
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) {
+    if (w == wave) xin = x;
+    x = apply(sh.tot[buf][w], x);
+  }
+  if (threadIdx.x == 0) sh.carry[buf ^ 1] = x;
+  return apply(ex, xin);
+}
+
+// Exclusive running sum over lanes (ascending thread order) continued across calls.
+__device__ __forceinline__ float2 block_exclusive_sum(float2 v, SharedSum &sh, int &nscan) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  v = cadd(v, sum_dpp<0x111, 0xF>(v));
+  v = cadd(v, sum_dpp<0x112, 0xF>(v));
+  v = cadd(v, sum_dpp<0x114, 0xF>(v));
+  v = cadd(v, sum_dpp<0x118, 0xF>(v));
+  v = cadd(v, sum_dpp<0x142, 0xA>(v));
+  v = cadd(v, sum_dpp<0x143, 0xC>(v));
+  const int buf = nscan & 1;
+  nscan++;
+  if (lane == 63) sh.tot[buf][wave] = v;
+  const float2 ex = sum_dpp<0x138, 0xF>(v);
+  __syncthreads();
+  float2 x = sh.carry[buf];
+  float2 xin = x;
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) {
+    if (w == wave) xin = x;
+    x = cadd(x, sh.tot[buf][w]);
+  }
+  if (threadIdx.x == 0) sh.carry[buf ^ 1] = x;
+  return cadd(xin, ex);
+}
+
+// g(d) = 88 tanh(d/88) - d
+__device__ __forceinline__ float soft_g(float d) {
+  if (fabsf(d) > 22.0f) return 88.0f * tanhf(d * (1.0f / 88.0f)) - d;
+  const float u = d * (1.0f / 88.0f);
+  const float s = u * u;
+  float p = fmaf(s, 1382.0f / 155925.0f, -62.0f / 2835.0f);
+  p = fmaf(s, p, 17.0f / 315.0f);
+  p = fmaf(s, p, -2.0f / 15.0f);
+  p = fmaf(s, p, 1.0f / 3.0f);
+  return -88.0f * u * s * p;
+}
+
+// For a ratio r: inv = 1/r, w = exp(g(-ln|r|))/r, tau = tanh^2(ln|r|/88)
+__device__ __forceinline__ void ratio_terms(float2 r, float2 &inv, float2 &w, float &tau) {
+  const float n = fmaf(r.x, r.x, r.y * r.y);
+  const float lnr = 0.5f * __logf(n);
+  const float ex = __expf(soft_g(-lnr));
+  const float rn = 1.0f / n;
+  inv = make_float2(r.x * rn, -r.y * rn);
+  w = make_float2(inv.x * ex, inv.y * ex);
+  const float th = tanhf(lnr * (1.0f / 88.0f));
+  tau = th * th;
+}
+
+// The map  x -> (c0 + y - tau Re y) * inv,  y = kk w x
+__device__ __forceinline__ Aff step_map(float kk, float2 w, float tau, float2 inv, float2 c0) {
+  const float2 cw = make_float2(kk * w.x, kk * w.y);
+  const float t1 = 1.0f - tau;
+  const float y00 = t1 * cw.x, y01 = -t1 * cw.y, y10 = cw.y, y11 = cw.x;
+  Aff m;
+  m.a00 = fmaf(inv.x, y00, -inv.y * y10);
+  m.a01 = fmaf(inv.x, y01, -inv.y * y11);
+  m.a10 = fmaf(inv.y, y00, inv.x * y10);
+  m.a11 = fmaf(inv.y, y01, inv.x * y11);
+  const float2 v = cmul(inv, c0);
+  m.v0 = v.x;
+  m.v1 = v.y;
+  return m;
+}
+
+// q = conj(h) G_raw for the output G = clip50(G_raw exp(g(ln|G_raw|))) and its cotangent gbar.
+__device__ __forceinline__ float2 cot_q(float2 Graw, float2 gbar) {
+  const float m2 = fmaf(Graw.x, Graw.x, Graw.y * Graw.y);
+  if (!(m2 > 0.0f)) return make_float2(0.f, 0.f);  // zeroed by the forward (not finite, or out of range)
+  const float L = 0.5f * __logf(m2);
+  const float F = __expf(soft_g(L));
+  const float2 Gc = make_float2(Graw.x * F, Graw.y * F);
+  const float2 X = make_float2(fmaf(gbar.x, Gc.x, gbar.y * Gc.y), fmaf(gbar.x, Gc.y, -gbar.y * Gc.x));  // conj(gbar) Gc
+  const float mc2 = m2 * F * F;
+  if (mc2 > 2500.0f) return make_float2(0.0f, X.y * 50.0f * rsqrtf(mc2));  // clipped: only the phase moves
+  const float th = tanhf(L * (1.0f / 88.0f));
+  return make_float2(X.x - th * th * X.x, X.y);
+}
+
+__device__ __forceinline__ float2 load_gbar(const float2 *gf, const float2 *gG, long i) {
+  float2 g = make_float2(0.f, 0.f);
+  if (gf) g = gf[i];
+  if (gG) { const float2 q = gG[i]; g.x += q.x; g.y += q.y; }
+  // a cotangent that is not a number counts as 0, as in the reference's backward (bk_core.py:321-325)
+  if (!(fabsf(g.x) <= 3.0e38f)) g.x = 0.f;
+  if (!(fabsf(g.y) <= 3.0e38f)) g.y = 0.f;
+  return g;
+}
+
+// Re(x D),  D = d reg(a - z)/d a,  reg(x) = x (1 + 1e-3/|x|)
+__device__ __forceinline__ float times_dreg(float2 x, float a, float2 z) {
+  const float xr = a - z.x, xi = -z.y;
+  const float n2 = fmaf(xr, xr, xi * xi);
+  if (!(n2 > 1e-24f)) return x.x;
+  const float inv = rsqrtf(n2);
+  const float f1 = fmaf(1e-3f, inv, 1.0f);
+  const float cf = 1e-3f * xr * inv * inv * inv;
+  return x.x * (f1 - cf * xr) + x.y * (cf * xi);
+}
+
+__device__ __forceinline__ float finite_or_zero(float v) { return fabsf(v) <= 3.0e38f ? v : 0.0f; }
+
+// ---- left -> right ------------------------------------------------------------------------------------------------
+template <int OFF>  // kphi_m = k_{m-OFF}
+__global__ __launch_bounds__(T) void bk_adjoint_phi_kernel(
+    const float *__restrict__ a_, long lda, const float *__restrict__ b_, long ldb, const float *__restrict__ c_,
+    long ldc, const float *__restrict__ z_dev, float z_re, float z_im, long N, const float2 *__restrict__ Graw_,
+    const float2 *__restrict__ gf_, const float2 *__restrict__ gG_, const float2 *__restrict__ s_,
+    float2 *__restrict__ P_, float *__restrict__ ga_, float *__restrict__ gk_) {
+  __shared__ SharedAff sha;
+  __shared__ SharedSum shs;
+  const long row = blockIdx.x;
+  const float *a = a_ + row * lda, *b = b_ + row * ldb, *c = c_ + row * ldc;
+  const float2 *Graw = Graw_ + row * N, *gf = gf_ ? gf_ + row * N : nullptr, *gG = gG_ ? gG_ + row * N : nullptr;
+  const float2 *sv = s_ + row * N;
+  float2 *P = P_ + row * N;
+  float *ga = ga_ + row * N;
+  float *gk = gk_ ? gk_ + row * (N - 1) : nullptr;
+  const float2 z = z_dev ? make_float2(z_dev[0], z_dev[1]) : make_float2(z_re, z_im);
+  const int t = threadIdx.x;
+  const int nch = (int)((N + CHUNK - 1) / CHUNK);
+  int nsum = 0, naff = 0;
+  if (t == 0) {
+    sha.carry[0] = make_float2(0.f, 0.f);
+    shs.carry[0] = make_float2(0.f, 0.f);
+  }
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
+    const long first = (long)ch * CHUNK + (long)t * EB;
+    float2 q[EB];
+    float2 sum = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+      const long j = first + e;
+      q[e] = make_float2(0.f, 0.f);
+      if (j < N) q[e] = cot_q(Graw[j], load_gbar(gf, gG, j));
+      sum = cadd(sum, q[e]);
+    }
+    float2 Prun = block_exclusive_sum(sum, shs, nsum);  // P_{first-1}
+    Aff st[EB];
+    float2 wv[EB];
+    Aff A = aff_identity();
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+      const long j = first + e;
+      st[e] = aff_identity();
+      wv[e] = make_float2(0.f, 0.f);
+      if (j >= 1 && j < N) {
+        float2 inv;
+        float tau;
+        ratio_terms(sv[j], inv, wv[e], tau);
+        const long ki = j - 1 - OFF;
+        const float kk = ki >= 0 ? b[ki] * c[ki] : 0.0f;
+        st[e] = step_map(kk, wv[e], tau, inv, Prun);  // c0 = P_{j-1}
+      }
+      Prun = cadd(Prun, q[e]);
+      if (j < N) P[j] = Prun;
+      A = compose(st[e], A);
+    }
+    float2 x = block_exclusive_aff(A, sha, naff);  // mu_{first-1} / s_{first-1}
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+      const long j = first + e;
+      if (j < N) {
+        const long ki = j - 1 - OFF;
+        if (gk && j >= 1 && ki >= 0) gk[ki] = -fmaf(x.x, wv[e].x, -x.y * wv[e].y);
+        x = apply(st[e], x);
+        ga[j] = j >= 1 ? times_dreg(x, a[j], z) : 0.0f;
+      }
+    }
+  }
+}
+
+// ---- right -> left ------------------------------------------------------------------------------------------------
+template <int OFF>
+__global__ __launch_bounds__(T) void bk_adjoint_theta_kernel(
+    const float *__restrict__ a_, long lda, const float *__restrict__ b_, long ldb, const float *__restrict__ c_,
+    long ldc, const float *__restrict__ z_dev, float z_re, float z_im, long N, const float2 *__restrict__ r_,
+    const float2 *__restrict__ P_, float *__restrict__ ga_, float *__restrict__ gb_, float *__restrict__ gc_) {
+  __shared__ SharedAff sha;
+  const long row = blockIdx.x;
+  const float *a = a_ + row * lda, *b = b_ + row * ldb, *c = c_ + row * ldc;
+  const float2 *rv = r_ + row * N, *P = P_ + row * N;
+  float *ga = ga_ + row * N;
+  float *gb = gb_ ? gb_ + row * (N - 1) : nullptr;
+  float *gc = gc_ ? gc_ + row * (N - 1) : nullptr;
+  const float2 z = z_dev ? make_float2(z_dev[0], z_dev[1]) : make_float2(z_re, z_im);
+  const int t = threadIdx.x;
+  const int nch = (int)((N + CHUNK - 1) / CHUNK);
+  int naff = 0;
+  if (t == 0) sha.carry[0] = make_float2(0.f, 0.f);
+  __syncthreads();
+  for (int ch = nch - 1; ch >= 0; --ch) {
+    const long first = (long)ch * CHUNK + (long)(T - 1 - t) * EB;  // descending segments over ascending threads
+    Aff st[EB];
+    float2 wv[EB];
+    Aff A = aff_identity();
+#pragma unroll
+    for (int qi = 0; qi < EB; ++qi) {
+      const int e = EB - 1 - qi;
+      const long j = first + e;
+      st[e] = aff_identity();
+      wv[e] = make_float2(0.f, 0.f);
+      if (j < N) {
+        float2 inv;
+        float tau;
+        ratio_terms(rv[j], inv, wv[e], tau);
+        const float kk = j < N - 1 ? b[j] * c[j] : 0.0f;
+        const float2 Pj = P[j];
+        st[e] = step_map(kk, wv[e], tau, inv, make_float2(-Pj.x, -Pj.y));
+      }
+      A = compose(st[e], A);
+    }
+    float2 x = block_exclusive_aff(A, sha, naff);  // lam_{j+1} / r_{j+1} for the lane's last element j
+#pragma unroll
+    for (int qi = 0; qi < EB; ++qi) {
+      const int e = EB - 1 - qi;
+      const long j = first + e;
+      if (j < N) {
+        const float gk_theta = -fmaf(x.x, wv[e].x, -x.y * wv[e].y);
+        x = apply(st[e], x);
+        ga[j] = finite_or_zero(ga[j] + times_dreg(x, a[j], z));
+        if (gb && j < N - 1) {
+          const float gk = gk_theta + (j + OFF <= N - 2 ? gb[j] : 0.0f);  // gb held the phi part of grad_k
+          gb[j] = finite_or_zero(c[j] * gk);
+          gc[j] = finite_or_zero(b[j] * gk);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t bkcore_backward_analytic_workspace_bytes(int64_t B, int64_t N) {
+  if (B <= 0 || N <= 0) return 0;
+  // forward scratch + G_raw + r + s + P  (complex64 each)
+  return ((bkcore_workspace_bytes(B, N) + 255) & ~(size_t)255) + 4 * (size_t)B * (size_t)N * 2 * sizeof(float);
+}
+
+int bkcore_backward_analytic(const float *a, int64_t lda, const float *b, int64_t ldb, const float *c, int64_t ldc,
+                             const float *z_dev, float z_re, float z_im, int64_t B, int64_t N,
+                             const float *grad_features, const float *grad_G, float *grad_a, float *grad_b,
+                             float *grad_c, void *workspace, size_t workspace_bytes, void *state, unsigned flags,
+                             void *stream) {
+  if (B < 0 || N < 0 || lda < 0 || ldb < 0 || ldc < 0) return BKCORE_EINVAL;
+  if (B == 0 || N == 0) return BKCORE_OK;
+  if (!a || !grad_a || (N > 1 && (!b || !c))) return BKCORE_EINVAL;
+  if ((grad_b == nullptr) != (grad_c == nullptr)) return BKCORE_EINVAL;
+  if (flags & ~BKCORE_FLAG_PHI_EXACT) return BKCORE_EINVAL;
+  if (N > bkcore_max_seq_len()) return BKCORE_ETOOLONG;
+  const size_t need = bkcore_backward_analytic_workspace_bytes(B, N);
+  if (!workspace || workspace_bytes < need) return BKCORE_EWORKSPACE;
+  char *ws = (char *)workspace;
+  const size_t fwd_ws = (bkcore_workspace_bytes(B, N) + 255) & ~(size_t)255;
+  const size_t plane = (size_t)B * (size_t)N * 2 * sizeof(float);
+  float *Graw = (float *)(ws + fwd_ws);
+  float *sr = (float *)(ws + fwd_ws + plane);
+  float *ss = (float *)(ws + fwd_ws + 2 * plane);
+  float *Pp = (float *)(ws + fwd_ws + 3 * plane);
+  // 1. the forward again, keeping the theta / phi ratios and G before its final clamps (inputs are already
+  //    sanitised, hence RAW)
+  const unsigned fflags = BKCORE_FLAG_RAW | (flags & BKCORE_FLAG_PHI_EXACT);
+  const int rc = bkcore_internal_forward_save(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, Graw, ws, state, fflags,
+                                              stream, sr, ss);
+  if (rc != BKCORE_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const float2 *gf = (const float2 *)grad_features, *gg = (const float2 *)grad_G;
+  float *gk = N > 1 ? grad_b : nullptr;
+  float *gc = N > 1 ? grad_c : nullptr;
+#define BK_LAUNCH_ADJ(OFF)                                                                                            \
+  hipLaunchKernelGGL((bk_adjoint_phi_kernel<OFF>), dim3((unsigned)B), dim3(T), 0, s, a, (long)lda, b, (long)ldb, c,  \
+                     (long)ldc, z_dev, z_re, z_im, (long)N, (const float2 *)Graw, gf, gg, (const float2 *)ss,         \
+                     (float2 *)Pp, grad_a, gk);                                                                       \
+  hipLaunchKernelGGL((bk_adjoint_theta_kernel<OFF>), dim3((unsigned)B), dim3(T), 0, s, a, (long)lda, b, (long)ldb,   \
+                     c, (long)ldc, z_dev, z_re, z_im, (long)N, (const float2 *)sr, (const float2 *)Pp, grad_a, gk, gc)
+  if (flags & BKCORE_FLAG_PHI_EXACT) {
+    BK_LAUNCH_ADJ(0);
+  } else {
+    BK_LAUNCH_ADJ(1);
+  }
+#undef BK_LAUNCH_ADJ
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return BKCORE_ELAUNCH;
+  return BKCORE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,14 @@
+// Functions shared between the translation units of libbkcore.so (not part of the public ABI).
+#ifndef BKCORE_INTERNAL_H
+#define BKCORE_INTERNAL_H
+#include <stddef.h>
+#include <stdint.h>
+
+// Float32 forward for the analytic backward: stores, per element, r_j = theta_{j+1}/theta_j and s_j = phi_j/phi_{j+1}
+// (complex64 each), and writes to G the resolvent diagonal BEFORE the final log-magnitude clamp and the |G| <= 50
+// clip (0 where |G_raw| is outside [1e-18, 1e18] or not a number).  Other arguments as bkcore_forward; no features.
+extern "C" __attribute__((visibility("hidden"))) int bkcore_internal_forward_save(
+    const float *a, int64_t lda, const float *b, int64_t ldb, const float *c, int64_t ldc, const float *z_dev,
+    float z_re, float z_im, int64_t B, int64_t N, float *G, void *workspace, void *state, unsigned flags, void *stream,
+    float *save_r, float *save_s);
+#endif

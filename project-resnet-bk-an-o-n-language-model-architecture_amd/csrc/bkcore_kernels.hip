@@ -32,6 +32,7 @@
 #include <stdint.h>
 
 #include "../../include/bkcore.h"
+#include "bkcore_internal.h"
 
 namespace {
 
@@ -72,6 +73,11 @@ __device__ __forceinline__ float2 cmad(float2 acc, float2 p, float2 q) {
 // al*x - ka*p   (one recurrence step; ka real)
 __device__ __forceinline__ float2 rstep(float2 al, float ka, float2 x, float2 p) {
   return make_float2(fmaf(al.x, x.x, fmaf(-al.y, x.y, -ka * p.x)), fmaf(al.x, x.y, fmaf(al.y, x.x, -ka * p.y)));
+}
+// p / q
+__device__ __forceinline__ float2 cdiv(float2 p, float2 q) {
+  const float inv = __builtin_amdgcn_rcpf(fmaf(q.x, q.x, q.y * q.y));
+  return make_float2(fmaf(p.x, q.x, p.y * q.y) * inv, fmaf(p.y, q.x, -p.x * q.y) * inv);
 }
 __device__ __forceinline__ float amax2(float2 p) { return fmaxf(fabsf(p.x), fabsf(p.y)); }
 __device__ __forceinline__ float2 ld2(float2 p, int e) { return make_float2(ldexpf(p.x, e), ldexpf(p.y, e)); }
@@ -346,9 +352,9 @@ __device__ __forceinline__ bool ratio_differs(const Vec &est, const Vec &x) {
 // tighter than the wall factor needs) and share the rescaling exponent.  The mantissas go to the lane's 16 slots
 // of the LDS output tile (`om`, consecutive), where the epilogue later replaces each by G in place; exponents
 // are shared by element pairs and stay in registers.
-template <bool TAIL>
+template <bool TAIL, bool SAVE>
 __device__ __forceinline__ void theta_lane(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask, Vec x,
-                                           float2 *__restrict__ om, int (&oe)[E / 2]) {
+                                           float2 *__restrict__ om, int (&oe)[E / 2], float2 *__restrict__ save_r) {
   float2 u0 = x.x0, u1 = x.x1;  // linear chain
   float l0 = log2_norm2(u0);
   float l1 = log2_norm2(u1);
@@ -361,6 +367,7 @@ __device__ __forceinline__ void theta_lane(const float2 (&al)[E], const float (&
     if (!TAIL || ((vmask >> j) & 1u)) {
       const float2 yu = rstep(al[j], kw[j], u0, u1);
       const float2 y = rstep(al[j], kk, x.x0, x.x1);
+      if (SAVE) save_r[j] = cdiv(y, x.x0);  // r_j = theta_{j+1} / theta_j, kept for the analytic backward
       u1 = u0;
       u0 = yu;
       x.x1 = x.x0;
@@ -615,17 +622,18 @@ __device__ __forceinline__ Vec two_pass(const float2 (&al)[E], const float (&kw)
   return x;
 }
 
-template <bool FAST, bool TAIL, int KO_PHI>
+template <bool FAST, bool TAIL, int KO_PHI, bool SAVE>
 __device__ __forceinline__ void sweepB_chunk(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask,
                                              const Vec &xt, float2 inv_det, int e_det, Shared &sh, ScanCtx &ctx,
-                                             int seg, bool &bad) {
+                                             int seg, bool &bad, float2 *__restrict__ save_r,
+                                             float2 *__restrict__ save_s) {
   float k2[E];
   Vec x = two_pass<FAST, true, TAIL, KO_PHI>(al, kw, vmask, k2, sh, ctx, bad);
   // theta of the lane's elements into the lane's slots of the output tile.  (All reads of the staged inputs
   // happened before the scans' barriers, so the tile may overwrite them; each slot is touched by this thread only.)
   float2 *slot = &sh.u.out_s[pad16(seg * E)];
   int the[E / 2];
-  theta_lane<TAIL>(al, kw, vmask, xt, slot, the);
+  theta_lane<TAIL, SAVE>(al, kw, vmask, xt, slot, the, save_r);
   // last phi re-run fused with the epilogue (bk_core.py:190-208): theta_i in the slot is replaced by G_i
 #pragma unroll
   for (int j = 0; j < E; ++j) {
@@ -634,10 +642,16 @@ __device__ __forceinline__ void sweepB_chunk(const float2 (&al)[E], const float 
     const int Ee = the[ei >> 1] + x.e - e_det;
     const float n = fmaf(P.x, P.x, P.y * P.y);
     const float L = LN2_HALF * fmaf(2.0f, (float)Ee, __builtin_amdgcn_logf(n));  // ln |G_raw|
-    const float sc = ldexpf(__builtin_amdgcn_exp2f(wall_exponent(L) * LOG2E), Ee);
-    float2 g = make_float2(P.x * sc, P.y * sc);
+    float2 g;
+    if (SAVE) {
+      // for the analytic backward: G_raw itself (no log-magnitude clamp, no clip); 0 outside 1e-18 <= |G_raw| <= 1e18
+      g = (fabsf(L) <= 41.4f) ? make_float2(ldexpf(P.x, Ee), ldexpf(P.y, Ee)) : make_float2(0.f, 0.f);
+    } else {
+      const float sc = ldexpf(__builtin_amdgcn_exp2f(wall_exponent(L) * LOG2E), Ee);
+      g = make_float2(P.x * sc, P.y * sc);
+    }
     const float m2 = fmaf(g.x, g.x, g.y * g.y);
-    if (__builtin_expect(!(m2 <= 2500.0f), 0)) {
+    if (!SAVE && __builtin_expect(!(m2 <= 2500.0f), 0)) {
       // |G| > 50: clipped to 50 G/|G| (bk_core.py:205-208; also when 2^Ee overflowed although G_raw is finite:
       // exp(88 tanh(L/88)) > 50 for every L > 4); anything that is not a number: 0 (bk_core.py:204)
       const float u = 50.0f * __builtin_amdgcn_rsqf(n);
@@ -646,6 +660,7 @@ __device__ __forceinline__ void sweepB_chunk(const float2 (&al)[E], const float 
     slot[ei] = g;
     if (!TAIL || ((vmask >> ei) & 1u)) {
       const float2 y = rstep(al[ei], k2[ei], x.x0, x.x1);
+      if (SAVE) save_s[ei] = cdiv(y, x.x0);  // s_i = phi_i / phi_{i+1} (phi_i = minor of rows i..N-1)
       x.x1 = x.x0;
       x.x0 = y;
       if ((j & 1) == 1) vnorm(x);
@@ -671,11 +686,12 @@ __host__ __device__ inline size_t rowflag_bytes(long B) { return (((size_t)B * s
 
 // FAST = first launch (fast pass 1, verified); !FAST = second launch: rows whose verification failed, or every row
 // when he_diag held a NaN and b/c held a NaN (then with b/c NaNs replaced by 1, bk_core.py:260-264).
-template <typename TIn, bool PHI_EXACT, bool FAST>
+template <typename TIn, bool PHI_EXACT, bool FAST, bool SAVE>
 __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
     const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
     const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, float2 *__restrict__ G_,
-    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, int second, unsigned flags) {
+    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, int second, unsigned flags,
+    float2 *__restrict__ save_r_, float2 *__restrict__ save_s_) {
   __shared__ Shared sh;
   const long row = blockIdx.x;
   int *rowflag = reinterpret_cast<int *>(ws);
@@ -763,10 +779,12 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
     const int seg = T - 1 - t;  // descending segments over ascending threads: phi's processing order
     fetch_elems(sh, base, seg, cfg, al, kw, vmask);
     const Vec xt = get_state(st, ch, seg);
+    float2 *sr = SAVE ? save_r_ + row * N + base + (long)seg * E : nullptr;
+    float2 *ss = SAVE ? save_s_ + row * N + base + (long)seg * E : nullptr;
     if (base + CHUNK <= N)
-      sweepB_chunk<FAST, false, KO_PHI>(al, kw, vmask, xt, inv_det, e_det, sh, ctx, seg, bad);
+      sweepB_chunk<FAST, false, KO_PHI, SAVE>(al, kw, vmask, xt, inv_det, e_det, sh, ctx, seg, bad, sr, ss);
     else
-      sweepB_chunk<FAST, true, KO_PHI>(al, kw, vmask, xt, inv_det, e_det, sh, ctx, seg, bad);
+      sweepB_chunk<FAST, true, KO_PHI, SAVE>(al, kw, vmask, xt, inv_det, e_det, sh, ctx, seg, bad, sr, ss);
     __syncthreads();
     // coalesced stores of G and features (same numbers, bk_core.py:296-298)
     float2 *__restrict__ Gc = G + base;
@@ -775,7 +793,7 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
 #pragma unroll
       for (int j = 0; j < E; ++j) {
         const int idx = t + j * T;
-        const float2 g = fix_tiny(sh.u.out_s[pad16(idx)]);
+        const float2 g = SAVE ? sh.u.out_s[pad16(idx)] : fix_tiny(sh.u.out_s[pad16(idx)]);
         Gc[idx] = g;
         if (Fc) Fc[idx] = g;
       }
@@ -785,7 +803,7 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
       for (int j = 0; j < E; ++j) {
         const int idx = t + j * T;
         if (idx < n_here) {
-          const float2 g = fix_tiny(sh.u.out_s[pad16(idx)]);
+          const float2 g = SAVE ? sh.u.out_s[pad16(idx)] : fix_tiny(sh.u.out_s[pad16(idx)]);
           Gc[idx] = g;
           if (Fc) Fc[idx] = g;
         }
@@ -878,10 +896,10 @@ int g_call_counter = 0;
 
 inline int chunks_of(int64_t N) { return (int)((N + CHUNK - 1) / CHUNK); }
 
-template <typename TIn, bool PHI_EXACT>
+template <typename TIn, bool PHI_EXACT, bool SAVE>
 int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
                     const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
-                    void *ws, void *state, unsigned flags, hipStream_t stream) {
+                    void *ws, void *state, unsigned flags, hipStream_t stream, float *save_r, float *save_s) {
   int call_id = 0;
   if (state) {
     call_id = __atomic_add_fetch(&g_call_counter, 1, __ATOMIC_RELAXED);
@@ -891,10 +909,10 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
     }
   }
 #define BK_LAUNCH(FASTV, SECOND)                                                                                     \
-  hipLaunchKernelGGL((bk_forward_kernel<TIn, PHI_EXACT, FASTV>), dim3((unsigned)B), dim3(T), 0, stream,              \
+  hipLaunchKernelGGL((bk_forward_kernel<TIn, PHI_EXACT, FASTV, SAVE>), dim3((unsigned)B), dim3(T), 0, stream,        \
                      (const TIn *)a, (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re,   \
                      z_im, (long)B, (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id,     \
-                     SECOND, flags)
+                     SECOND, flags, (float2 *)save_r, (float2 *)save_s)
   if (state) {
     // fast first launch, then the (normally empty) second launch for rows that need the two-scan path
     BK_LAUNCH(true, 0);
@@ -925,8 +943,10 @@ int launch_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const
                    const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
                    void *ws, void *state, unsigned flags, hipStream_t s) {
   if (flags & BKCORE_FLAG_PHI_EXACT)
-    return launch_forward2<TIn, true>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state, flags, s);
-  return launch_forward2<TIn, false>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state, flags, s);
+    return launch_forward2<TIn, true, false>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
+                                             flags, s, nullptr, nullptr);
+  return launch_forward2<TIn, false, false>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
+                                            flags, s, nullptr, nullptr);
 }
 
 }  // namespace
@@ -965,6 +985,18 @@ int bkcore_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const
   }
 }
 
+int bkcore_internal_forward_save(const float *a, int64_t lda, const float *b, int64_t ldb, const float *c, int64_t ldc,
+                                 const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G,
+                                 void *workspace, void *state, unsigned flags, void *stream, float *save_r,
+                                 float *save_s) {
+  hipStream_t s = (hipStream_t)stream;
+  if (flags & BKCORE_FLAG_PHI_EXACT)
+    return launch_forward2<float, true, true>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, nullptr, workspace,
+                                              state, flags, s, save_r, save_s);
+  return launch_forward2<float, false, true>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, nullptr, workspace,
+                                             state, flags, s, save_r, save_s);
+}
+
 int bkcore_backward_ref(const float *G, const float *grad_features, const float *grad_G, float alpha, int64_t n,
                         float *grad_a, void *stream) {
   if (n < 0) return BKCORE_EINVAL;
@@ -995,7 +1027,7 @@ int bkcore_backward_ref(const float *G, const float *grad_features, const float 
 
 int64_t bkcore_max_seq_len(void) { return (int64_t)MAX_N; }
 int bkcore_last_hip_error(void) { return g_last_hip_error; }
-int bkcore_abi_version(void) { return 3; }
+int bkcore_abi_version(void) { return 4; }
 
 const char *bkcore_error_string(int code) {
   switch (code) {

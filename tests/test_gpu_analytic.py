@@ -1,0 +1,188 @@
+"""GPU tests of the analytic backward (gradients for he_diag, h0_super, h0_sub) through the C ABI.
+
+Checked against (1) the gradients torch.autograd produced through the reference's own sequential forward in float64,
+recorded in the golden fixtures, and (2) the float64 adjoint specification (itself pinned to those fixtures and to
+autograd through the oracle by tests/test_analytic_adjoint.py) at sizes up to N = 32768.
+Tolerance: 1e-4, measured per tensor as max |x - ref| / max |ref| (gradients have zero crossings, so an
+elementwise relative error is not meaningful)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.bk_analytic_adjoint import adjoint_grads
+from test_oracle_golden import ALL
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+FINITE = [n for n in ALL if n not in ("poisoned", "nan_offdiag_only")]
+# fixtures whose float32 forward itself is at the edge of the 1e-4 budget (ill-conditioned rows: |G| reaches the clip)
+ILL = {"bench_randn": 2e-3, "varying_bc_small": 2e-3, "diag_only": 2e-3, "diag_only_bf16": 2e-3}
+
+
+@pytest.fixture(scope="module")
+def bk():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import bkcore
+    yield bkcore
+    bkcore.BKCoreFunction.GRAD_MODE = "reference"
+    bkcore.BKCoreFunction.PHI_K_INDEX = "reference"
+
+
+def rel(x, ref):
+    ref = np.asarray(ref)
+    if ref.size == 0:
+        return 0.0
+    return float(np.abs(np.asarray(x) - ref).max() / max(np.abs(ref).max(), 1e-300))
+
+
+def _dev(x, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dtype).cuda()
+
+
+@pytest.mark.parametrize("name", FINITE)
+def test_golden_true_gradients(bk, golden, name):
+    cs = golden[name]
+    a = _dev(np.clip(cs["a"].astype(np.float64), -100, 100))
+    b = _dev(np.clip(cs["b"].astype(np.float64), -10, 10))
+    c = _dev(np.clip(cs["c"].astype(np.float64), -10, 10))
+    z = complex(*cs["z"])
+    ga, gb, gc = bk.bk_backward_analytic(a, b, c, z, _dev(cs["gfeat"]), None)
+    tol = ILL.get(name, TOL)
+    if name.endswith("bf16"):
+        pytest.skip("fixture inputs are bf16-rounded copies; covered by diag_only")
+    assert rel(ga.cpu().numpy(), cs["grad_true_a"]) <= tol
+    assert rel(gb.cpu().numpy(), cs["grad_true_b"]) <= tol
+    assert rel(gc.cpu().numpy(), cs["grad_true_c"]) <= tol
+
+
+def _case(B, N, seed, dtype=torch.float64):
+    g = torch.Generator().manual_seed(seed)
+    a = -2.0 + 0.5 * torch.randn(B, N, generator=g, dtype=dtype)
+    b = 1.0 + 0.1 * torch.randn(B, N - 1, generator=g, dtype=dtype)
+    c = 1.0 + 0.1 * torch.randn(B, N - 1, generator=g, dtype=dtype)
+    gf = torch.randn(B, N, 2, generator=g, dtype=dtype)
+    gG = torch.complex(torch.randn(B, N, generator=g, dtype=dtype), torch.randn(B, N, generator=g, dtype=dtype))
+    return a.float().double(), b.float().double(), c.float().double(), gf.float().double(), gG.to(torch.complex64).to(torch.complex128)
+
+
+@pytest.mark.parametrize("conv", ["reference", "exact"])
+@pytest.mark.parametrize("B,N,z", [(3, 1, 1j), (3, 2, 1j), (2, 7, 0.5j), (3, 2047, 1j), (3, 2048, 1j), (3, 2049, 1j),
+                                   (2, 6000, 0.3 + 0.5j), (2, 32768, 1j)])
+def test_operator_autograd_matches_adjoint(bk, B, N, z, conv):
+    a, b, c, gf, gG = _case(B, N, 7 + N)
+    gbar = (gf[..., 0] + 1j * gf[..., 1] + gG).numpy()
+    ra, rb, rc, G = adjoint_grads(a.numpy(), b.numpy(), c.numpy(), z, gbar, conv)
+    bk.BKCoreFunction.GRAD_MODE = "analytic"
+    bk.BKCoreFunction.PHI_K_INDEX = conv
+    try:
+        ad = a.float().cuda().requires_grad_()
+        bd = b.float().cuda().requires_grad_()
+        cd = c.float().cuda().requires_grad_()
+        feats, Gd = bk.BKCoreFunction.apply(ad, bd, cd, torch.tensor(z, dtype=torch.complex64, device="cuda"))
+        gGd = gG.to(torch.complex64).cuda()
+        loss = (feats * gf.float().cuda()).sum() + (Gd.real * gGd.real + Gd.imag * gGd.imag).sum()
+        loss.backward()
+    finally:
+        bk.BKCoreFunction.GRAD_MODE = "reference"
+        bk.BKCoreFunction.PHI_K_INDEX = "reference"
+    assert rel(Gd.detach().cpu().numpy(), G) <= TOL
+    assert ad.grad.dtype == torch.float32 and ad.grad.shape == (B, N)
+    assert rel(ad.grad.cpu().numpy(), ra) <= TOL
+    assert rel(bd.grad.cpu().numpy(), rb) <= TOL
+    assert rel(cd.grad.cpu().numpy(), rc) <= TOL
+
+
+def test_coherent_cotangent(bk):
+    """All-ones cotangent: the prefix sums grow with N and the two adjoints cancel in the far field; float32 keeps
+    1e-3 at N = 8192 (stated, looser than TOL)."""
+    B, N, z = 2, 8192, 1j
+    a, b, c, _, _ = _case(B, N, 99)
+    gbar = np.ones((B, N), np.complex128)
+    ra, rb, rc, _ = adjoint_grads(a.numpy(), b.numpy(), c.numpy(), z, gbar, "reference")
+    gf = torch.zeros(B, N, 2)
+    gf[..., 0] = 1.0
+    ga, gb, gc = bk.bk_backward_analytic(a.float().cuda(), b.float().cuda(), c.float().cuda(), z, gf.cuda(), None)
+    assert rel(ga.cpu().numpy(), ra) <= 1e-3
+    assert rel(gb.cpu().numpy(), rb) <= 1e-3
+    assert rel(gc.cpu().numpy(), rc) <= 1e-3
+
+
+def test_expanded_offdiagonals_and_clamp_mask(bk):
+    """The layer's call pattern: (N-1,) buffers expand()ed over the batch (reference resnet_bk.py:155-157) receive
+    the batch-summed gradient; entries the input clamp saturated receive none."""
+    B, N, z = 4, 300, 1j
+    a, b, c, gf, _ = _case(B, N, 5)
+    a[0, 10] = 150.0                                            # clamped to 100 by the operator
+    b1 = b[0].clone()
+    c1 = c[0].clone()
+    ac = a.clamp(-100, 100)
+    ra, rb, rc, _ = adjoint_grads(ac.numpy(), b1.expand(B, -1).numpy(), c1.expand(B, -1).numpy(), z,
+                                  (gf[..., 0] + 1j * gf[..., 1]).numpy(), "reference")
+    ra[0, 10] = 0.0
+    bk.BKCoreFunction.GRAD_MODE = "analytic"
+    try:
+        ad = a.float().cuda().requires_grad_()
+        bp = b1.float().cuda().requires_grad_()
+        cp = c1.float().cuda().requires_grad_()
+        feats, _ = bk.BKCoreFunction.apply(ad, bp.unsqueeze(0).expand(B, -1), cp.unsqueeze(0).expand(B, -1), z)
+        (feats * gf.float().cuda()).sum().backward()
+    finally:
+        bk.BKCoreFunction.GRAD_MODE = "reference"
+    assert rel(ad.grad.cpu().numpy(), ra) <= TOL
+    assert ad.grad[0, 10].item() == 0.0
+    assert rel(bp.grad.cpu().numpy(), rb.sum(0)) <= TOL
+    assert rel(cp.grad.cpu().numpy(), rc.sum(0)) <= TOL
+
+
+def test_only_he_diag_needs_grad_and_bf16(bk):
+    B, N, z = 2, 500, 1j
+    a, b, c, gf, _ = _case(B, N, 11)
+    a16 = a.to(torch.bfloat16)
+    ra, _, _, _ = adjoint_grads(a16.double().numpy(), b.to(torch.bfloat16).double().numpy(),
+                                c.to(torch.bfloat16).double().numpy(), z, (gf[..., 0] + 1j * gf[..., 1]).numpy(),
+                                "reference")
+    bk.BKCoreFunction.GRAD_MODE = "analytic"
+    try:
+        ad = a16.cuda().requires_grad_()
+        feats, _ = bk.BKCoreFunction.apply(ad, b.to(torch.bfloat16).cuda(), c.to(torch.bfloat16).cuda(), z)
+        (feats * gf.float().cuda()).sum().backward()
+    finally:
+        bk.BKCoreFunction.GRAD_MODE = "reference"
+    assert ad.grad.dtype == torch.bfloat16
+    assert rel(ad.grad.float().cpu().numpy(), ra) <= 1e-2        # the gradient itself is rounded to bf16 (2^-8)
+
+
+def test_magnitude_clip_gradient(bk):
+    a = np.array([[0.0, 0.3, -0.2, 0.1]])
+    b = np.full((1, 3), 0.05)
+    c = np.full((1, 3), 0.05)
+    z = 0.005j
+    gbar = np.array([[1.0 + 0.5j, -0.3 + 1j, 0.7 - 0.2j, 0.1 + 0.1j]])
+    ra, rb, rc, G = adjoint_grads(a, b, c, z, gbar, "reference")
+    gf = _dev(np.stack([gbar.real, gbar.imag], -1))
+    ga, gb, gc = bk.bk_backward_analytic(_dev(a), _dev(b), _dev(c), z, gf, None)
+    assert rel(ga.cpu().numpy(), ra) <= TOL
+    assert rel(gb.cpu().numpy(), rb) <= TOL
+    assert rel(gc.cpu().numpy(), rc) <= TOL
+
+
+def test_argument_checks(bk):
+    from bkcore import _lib
+    L = _lib.load()
+    a = torch.zeros(2, 64, device="cuda")
+    b = torch.ones(2, 63, device="cuda")
+    ga = torch.empty(2, 64, device="cuda")
+    ws = torch.empty(256, dtype=torch.uint8, device="cuda")
+    rc = L.bkcore_backward_analytic(a.data_ptr(), 64, b.data_ptr(), 63, b.data_ptr(), 63, None, 0.0, 1.0, 2, 64,
+                                    None, None, ga.data_ptr(), None, None, ws.data_ptr(), 256, None, 0, None)
+    assert rc == _lib.EWORKSPACE
+    rc = L.bkcore_backward_analytic(a.data_ptr(), 64, b.data_ptr(), 63, b.data_ptr(), 63, None, 0.0, 1.0, 2, 64,
+                                    None, None, ga.data_ptr(), ga.data_ptr(), None, ws.data_ptr(), 256, None, 0, None)
+    assert rc == _lib.EINVAL
+    with pytest.raises(RuntimeError):
+        bk.bk_backward_analytic(a.cpu(), b.cpu(), b.cpu(), 1j, None, None)
+    empty = bk.bk_backward_analytic(torch.zeros(0, 8, device="cuda"), torch.zeros(0, 7, device="cuda"),
+                                    torch.zeros(0, 7, device="cuda"), 1j, None, None)
+    assert empty[0].shape == (0, 8)
