@@ -31,6 +31,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/bkcore.h"
 #include "bkcore_internal.h"
 
@@ -618,7 +620,8 @@ __device__ __forceinline__ Vec two_pass(const float2 (&al)[E], const float (&kw)
   }
   const Mat A2 = wall_and_aggregate<REV, TAIL, KO>(al, kw, vmask, est, k2);
   const Vec x = block_exclusive(A2, 1, sh, ctx);
-  if (FAST) bad |= ratio_differs(est, x);
+  // (a lane past the end of the row has no element that uses its estimate)
+  if (FAST) bad |= (!TAIL || vmask != 0u) && ratio_differs(est, x);
   return x;
 }
 
@@ -681,6 +684,96 @@ __device__ __forceinline__ float2 fix_tiny(float2 g) {
   return g;
 }
 
+// ---- the two sweeps over a range of chunks ---------------------------------------------------------------------
+// Three kinds of chunk: the row's first (no k to its left), interior ones (every load in range: no bounds logic),
+// and the row's last (ragged end).  Each kind is handled outside the loop over interior chunks, so that loop's body
+// holds a single variant of the staging and scan code.
+template <bool V>
+using BoolC = std::integral_constant<bool, V>;
+
+// Sweep A over chunks [ch0, ch1), left -> right: theta.  The running carries (sh.carry[*][ctx.cpar[*]]) must hold
+// the state entering chunk ch0; on return they hold the state after chunk ch1 - 1 (after a barrier).
+template <typename TIn, bool FAST>
+__device__ __forceinline__ void sweepA_range(const TIn *__restrict__ a, const TIn *__restrict__ b,
+                                             const TIn *__restrict__ c, const RowCfg &cfg, Shared &sh, ScanCtx &ctx,
+                                             float *__restrict__ st, int ch0, int ch1, unsigned &seen, bool &bad) {
+  const int t = threadIdx.x;
+  const int nch = (int)((cfg.N + CHUNK - 1) / CHUNK);
+  auto one = [&](auto full, auto tail, int ch) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full)::value, TAIL = decltype(tail)::value;
+    const long base = (long)ch * CHUNK;
+    float2 al[E];
+    float kw[E + 1];
+    unsigned vmask;
+    __syncthreads();  // previous chunk's LDS reads done
+    seen |= stage_chunk<TIn, FULL>(a, b, c, base, cfg, sh);
+    __syncthreads();
+    fetch_elems(sh, base, t, cfg, al, kw, vmask);
+    float k2[E];
+    const Vec x = two_pass<FAST, false, TAIL, 0>(al, kw, vmask, k2, sh, ctx, bad);
+    put_state(st, ch, t, x);
+  };
+  int ch = ch0;
+  if (ch < ch1 && ch == 0 && nch > 1) {
+    one(BoolC<false>{}, BoolC<false>{}, ch);
+    ++ch;
+  }
+  const int interior_end = min(ch1, nch - 1);
+  for (; ch < interior_end; ++ch) one(BoolC<true>{}, BoolC<false>{}, ch);
+  if (ch < ch1) one(BoolC<false>{}, BoolC<true>{}, ch);  // the row's last chunk
+}
+
+// Sweep B over chunks [ch0, ch1), right -> left: phi with running carry, theta from the stored lane states,
+// epilogue with the factor inv_det * 2^-e_det, coalesced stores of G and features.
+template <typename TIn, bool FAST, int KO_PHI, bool SAVE>
+__device__ __forceinline__ void sweepB_range(const TIn *__restrict__ a, const TIn *__restrict__ b,
+                                             const TIn *__restrict__ c, const RowCfg &cfg, Shared &sh, ScanCtx &ctx,
+                                             const float *__restrict__ st, int ch0, int ch1, float2 inv_det, int e_det,
+                                             float2 *__restrict__ G, float2 *__restrict__ F,
+                                             float2 *__restrict__ save_r, float2 *__restrict__ save_s, bool &bad) {
+  const int t = threadIdx.x;
+  const long N = cfg.N;
+  const int nch = (int)((N + CHUNK - 1) / CHUNK);
+  auto one = [&](auto full, auto tail, int ch) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full)::value, TAIL = decltype(tail)::value;
+    const long base = (long)ch * CHUNK;
+    float2 al[E];
+    float kw[E + 1];
+    unsigned vmask;
+    __syncthreads();  // previous chunk's out_s reads done (and lane states visible)
+    stage_chunk<TIn, FULL>(a, b, c, base, cfg, sh);
+    __syncthreads();
+    const int seg = T - 1 - t;  // descending segments over ascending threads: phi's processing order
+    fetch_elems(sh, base, seg, cfg, al, kw, vmask);
+    const Vec xt = get_state(st, ch, seg);
+    float2 *sr = SAVE ? save_r + base + (long)seg * E : nullptr;
+    float2 *ss = SAVE ? save_s + base + (long)seg * E : nullptr;
+    sweepB_chunk<FAST, TAIL, KO_PHI, SAVE>(al, kw, vmask, xt, inv_det, e_det, sh, ctx, seg, bad, sr, ss);
+    __syncthreads();
+    // coalesced stores of G and features (same numbers, bk_core.py:296-298)
+    float2 *__restrict__ Gc = G + base;
+    float2 *__restrict__ Fc = F ? F + base : nullptr;
+    const int n_here = TAIL ? (int)min((long)CHUNK, N - base) : CHUNK;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      const int idx = t + j * T;
+      if (!TAIL || idx < n_here) {
+        const float2 g = SAVE ? sh.u.out_s[pad16(idx)] : fix_tiny(sh.u.out_s[pad16(idx)]);
+        Gc[idx] = g;
+        if (Fc) Fc[idx] = g;
+      }
+    }
+  };
+  int ch = ch1 - 1;
+  if (ch >= ch0 && ch == nch - 1) {  // the row's last chunk
+    one(BoolC<false>{}, BoolC<true>{}, ch);
+    --ch;
+  }
+  const int interior_begin = max(ch0, 1);
+  for (; ch >= interior_begin; --ch) one(BoolC<true>{}, BoolC<false>{}, ch);
+  if (ch >= ch0 && ch == 0) one(BoolC<false>{}, BoolC<false>{}, 0);
+}
+
 // Workspace layout: B ints (per-row verdict of the fast path), padded to 256 bytes, then the lane states.
 __host__ __device__ inline size_t rowflag_bytes(long B) { return (((size_t)B * sizeof(int)) + 255) & ~(size_t)255; }
 
@@ -725,33 +818,13 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
   ctx.cpar[1] = 0;
   unsigned seen = 0;
   bool bad = false;
-  float2 al[E];
-  float kw[E + 1];
-  unsigned vmask;
 
   // ---- sweep A: theta; each lane's incoming state per chunk is stored
   if (t == 0) {
     sh.carry[0][0] = vec_start();
     sh.carry[1][0] = vec_start();
   }
-  for (int ch = 0; ch < nch; ++ch) {
-    const long base = (long)ch * CHUNK;
-    __syncthreads();  // previous chunk's LDS reads done
-    const bool full = base > 0 && base + CHUNK <= N - 1;
-    if (full)
-      seen |= stage_chunk<TIn, true>(a, b, c, base, cfg, sh);
-    else
-      seen |= stage_chunk<TIn, false>(a, b, c, base, cfg, sh);
-    __syncthreads();
-    fetch_elems(sh, base, t, cfg, al, kw, vmask);
-    float k2[E];
-    Vec x;
-    if (base + CHUNK <= N)
-      x = two_pass<FAST, false, false, 0>(al, kw, vmask, k2, sh, ctx, bad);
-    else
-      x = two_pass<FAST, false, true, 0>(al, kw, vmask, k2, sh, ctx, bad);
-    put_state(st, ch, t, x);
-  }
+  sweepA_range<TIn, FAST>(a, b, c, cfg, sh, ctx, st, 0, nch, seen, bad);
   // theta_N = first component of the pass-2 state after the last element
   __syncthreads();
   const Vec cdet = sh.carry[1][ctx.cpar[1]];
@@ -767,49 +840,8 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
     sh.carry[1][ctx.cpar[1]] = vec_start();
   }
   constexpr int KO_PHI = PHI_EXACT ? 1 : 0;
-  for (int ch = nch - 1; ch >= 0; --ch) {
-    const long base = (long)ch * CHUNK;
-    __syncthreads();  // previous chunk's out_s reads done (and lane states visible)
-    const bool full = base > 0 && base + CHUNK <= N - 1;
-    if (full)
-      stage_chunk<TIn, true>(a, b, c, base, cfg, sh);
-    else
-      stage_chunk<TIn, false>(a, b, c, base, cfg, sh);
-    __syncthreads();
-    const int seg = T - 1 - t;  // descending segments over ascending threads: phi's processing order
-    fetch_elems(sh, base, seg, cfg, al, kw, vmask);
-    const Vec xt = get_state(st, ch, seg);
-    float2 *sr = SAVE ? save_r_ + row * N + base + (long)seg * E : nullptr;
-    float2 *ss = SAVE ? save_s_ + row * N + base + (long)seg * E : nullptr;
-    if (base + CHUNK <= N)
-      sweepB_chunk<FAST, false, KO_PHI, SAVE>(al, kw, vmask, xt, inv_det, e_det, sh, ctx, seg, bad, sr, ss);
-    else
-      sweepB_chunk<FAST, true, KO_PHI, SAVE>(al, kw, vmask, xt, inv_det, e_det, sh, ctx, seg, bad, sr, ss);
-    __syncthreads();
-    // coalesced stores of G and features (same numbers, bk_core.py:296-298)
-    float2 *__restrict__ Gc = G + base;
-    float2 *__restrict__ Fc = F ? F + base : nullptr;
-    if (base + CHUNK <= N) {
-#pragma unroll
-      for (int j = 0; j < E; ++j) {
-        const int idx = t + j * T;
-        const float2 g = SAVE ? sh.u.out_s[pad16(idx)] : fix_tiny(sh.u.out_s[pad16(idx)]);
-        Gc[idx] = g;
-        if (Fc) Fc[idx] = g;
-      }
-    } else {
-      const int n_here = (int)(N - base);
-#pragma unroll
-      for (int j = 0; j < E; ++j) {
-        const int idx = t + j * T;
-        if (idx < n_here) {
-          const float2 g = SAVE ? sh.u.out_s[pad16(idx)] : fix_tiny(sh.u.out_s[pad16(idx)]);
-          Gc[idx] = g;
-          if (Fc) Fc[idx] = g;
-        }
-      }
-    }
-  }
+  sweepB_range<TIn, FAST, KO_PHI, SAVE>(a, b, c, cfg, sh, ctx, st, 0, nch, inv_det, e_det, G, F,
+                                        SAVE ? save_r_ + row * N : nullptr, SAVE ? save_s_ + row * N : nullptr, bad);
   if (FAST) {
     // verdict of the fast path for this row; the second launch recomputes the rows that failed
     const int any_bad = __syncthreads_or(bad ? 1 : 0);
@@ -821,6 +853,406 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
   if (state && !second && seen) {
     if (seen & 1u) __hip_atomic_store(&state[0], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (seen & 2u) __hip_atomic_store(&state[1], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---- long rows, few of them: several workgroups per row --------------------------------------------------------
+// With B below the number of workgroups the chip holds, a row is cut into S segments of `seg_ch` chunks and each
+// (row, segment) gets its own workgroup.  A segment cannot know the state entering it, but it does not need to:
+//   * the recurrences' wall factors and all ratios of consecutive terms depend on the entering state only through
+//     the entering RATIO, and wherever the ratio map contracts that ratio is fixed by the few hundred elements
+//     before the segment.  It is estimated by running the recurrence serially over the WARM elements on the far
+//     side of the boundary, starting from the start vector;
+//   * started from (ratio, 1), the segment's terms are the true ones up to one complex factor per segment.
+// bk_split_aggregate_kernel runs sweep A over each segment (storing lane states as the one-workgroup kernel does)
+// and a phi scan without outputs, and records each segment's final states.  bk_split_combine_kernel walks the
+// segments of a row: it checks every estimate against the true ratio coming out of the neighbouring segment,
+// accumulates the per-segment factors of theta and phi, and from them the factor theta_N^-1 * C_s * D_s that
+// bk_split_output_kernel (sweep B over each segment) applies in the epilogue.  A row with any failed check --
+// these or the per-lane checks of the fast path -- is flagged and recomputed by the one-workgroup two-scan kernel.
+constexpr int WARM = 128;          // elements of serial warm-up at a segment boundary
+constexpr int SEG_INFO = 32;       // floats of per-segment record
+// record layout (floats): [0..4] theta out, [5..9] phi out, [10..14] theta start, [15..19] phi start,
+//                         [20,21] factor mantissa, [22] factor exponent (as -e), [23] failed check in this segment,
+//                         [24,25,26] running theta factor (combine kernel scratch)
+
+__device__ __forceinline__ void put_vec(float *p, const Vec &x) {
+  p[0] = x.x0.x; p[1] = x.x0.y; p[2] = x.x1.x; p[3] = x.x1.y; p[4] = __int_as_float(x.e);
+}
+__device__ __forceinline__ Vec get_vec(const float *p) {
+  Vec x;
+  x.x0 = make_float2(p[0], p[1]);
+  x.x1 = make_float2(p[2], p[3]);
+  x.e = __float_as_int(p[4]);
+  return x;
+}
+
+__device__ __forceinline__ float2 reg_alpha(float a, const RowCfg &cfg) {
+  const float xr = a - cfg.z.x, xi = -cfg.z.y;
+  const float n = fmaf(xr, xr, xi * xi);
+  float f = fmaf(1e-3f, __builtin_amdgcn_rsqf(n), 1.0f);
+  float add = 0.0f;
+  if (!(n >= 1e-24f)) { f = 1.0f; add = 1e-3f; }
+  return make_float2(fmaf(xr, f, add), xi * f);
+}
+
+// Boundary warm-up: the recurrence run serially over `count` <= WARM elements i_first, i_first + dir, ... from the
+// start vector, wall factor included; the step at element i uses k_{i-1+ko}.  warm_stage: one thread loads and
+// regularises element number n into the LDS arrays at `wa`; warm_loop: one wave runs the serial loop (two chains
+// as in theta_lane: a linear one that supplies the wall factor off the critical path, and the corrected one) and
+// returns the final pair of terms with exponent 0.  A NaN in b or c stays NaN (such a row fails its checks and is
+// recomputed by the kernel that implements the sanitising rules).
+template <typename TIn>
+__device__ __forceinline__ void warm_stage(const TIn *__restrict__ a, const TIn *__restrict__ b,
+                                           const TIn *__restrict__ c, const RowCfg &cfg, long i_first, int dir, int ko,
+                                           float *wa, int n) {
+  const long i = i_first + (long)dir * n;
+  float av = to_f32<TIn>(a[i]);
+  const long j = i - 1 + ko;
+  float kk = 0.0f;
+  if (j >= 0 && j <= cfg.N - 2) {
+    float bv = to_f32<TIn>(b[j]), cv = to_f32<TIn>(c[j]);
+    if (!cfg.raw) {
+      bv = clamp_keep_nan(bv, 10.0f);
+      cv = clamp_keep_nan(cv, 10.0f);
+    }
+    kk = bv * cv;
+  }
+  if (!cfg.raw) {
+    av = clamp_keep_nan(av, 100.0f);
+    if (av != av) av = 0.0f;
+  }
+  const float2 al = reg_alpha(av, cfg);
+  wa[n] = al.x;
+  wa[WARM + n] = al.y;
+  wa[2 * WARM + n] = kk;
+}
+
+__device__ __forceinline__ Vec warm_loop(const float *wa, int count) {
+  Vec x = vec_start();
+  float2 u0 = x.x0, u1 = x.x1;
+  float l0 = log2_norm2(u0);
+  float l1 = log2_norm2(u1);
+#pragma unroll 4
+  for (int n = 0; n < count; ++n) {
+    const float2 al = make_float2(wa[n], wa[WARM + n]);
+    const float k = wa[2 * WARM + n];
+    const float d = LN2_HALF * (l1 - l0);
+    const float kk = k * wall_corr(d);
+    const float2 yu = rstep(al, k, u0, u1);
+    const float2 y = rstep(al, kk, x.x0, x.x1);
+    u1 = u0;
+    u0 = yu;
+    x.x1 = x.x0;
+    x.x0 = y;
+    l1 = l0;
+    if ((n & 1) == 1) {
+      const int de = expo(fmaxf(amax2(x.x0), amax2(x.x1)));
+      const float sc = pow2_neg(de);
+      x.x0 = sc2(x.x0, sc);
+      x.x1 = sc2(x.x1, sc);
+      u0 = sc2(u0, sc);
+      u1 = sc2(u1, sc);
+      l1 -= 2.0f * (float)de;
+    }
+    l0 = log2_norm2(u0);
+  }
+  vnorm(x);
+  x.e = 0;
+  return x;
+}
+
+// |est ratio - true ratio| > 2e-5 |true ratio| (also true when anything is not a number)
+__device__ __forceinline__ bool ratio_differs_tight(const Vec &est, const Vec &x) {
+  const float2 c = cmul(est.x0, x.x1);
+  const float2 d = cmul(x.x0, est.x1);
+  const float dx = c.x - d.x, dy = c.y - d.y;
+  const float lhs = fmaf(dx, dx, dy * dy);
+  const float rhs = 4.0e-10f * fmaf(d.x, d.x, d.y * d.y);
+  return !(lhs <= rhs);
+}
+
+__host__ __device__ inline size_t lane_state_bytes(long B, long N) {
+  return (size_t)B * (size_t)((N + CHUNK - 1) / CHUNK) * 5 * T * sizeof(float);
+}
+
+template <typename TIn, bool PHI_EXACT>
+__global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_split_aggregate_kernel(
+    const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
+    const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, char *__restrict__ ws, int *state,
+    int call_id, unsigned flags, int S, int seg_ch) {
+  __shared__ Shared sh;
+  const long row = blockIdx.x / S;
+  const int sg = blockIdx.x % S;
+  const TIn *a = a_ + row * lda;
+  const TIn *b = b_ + row * ldb;
+  const TIn *c = c_ + row * ldc;
+  const int nch = (int)((N + CHUNK - 1) / CHUNK);
+  const int ch0 = sg * seg_ch;
+  const int ch1 = min(nch, ch0 + seg_ch);
+  float *st = reinterpret_cast<float *>(ws + rowflag_bytes(B)) + row * (long)nch * 5 * T;
+  float *info = reinterpret_cast<float *>(ws + rowflag_bytes(B) + lane_state_bytes(B, N)) + (row * S + sg) * SEG_INFO;
+  RowCfg cfg;
+  cfg.z = z_dev ? make_float2(z_dev[0], z_dev[1]) : make_float2(z_re, z_im);
+  cfg.N = N;
+  cfg.raw = (flags & BKCORE_FLAG_RAW) != 0;
+  cfg.fix_bc = false;
+  const int t = threadIdx.x;
+  ScanCtx ctx;
+  ctx.nscan = 0;
+  ctx.cpar[0] = 0;
+  ctx.cpar[1] = 0;
+  unsigned seen = 0;
+  bool bad = false;
+  constexpr int KO_PHI = PHI_EXACT ? 1 : 0;
+
+  // both boundary warm-ups at once: threads 0..WARM-1 stage theta's elements and wave 0 runs its loop, threads
+  // WARM..2 WARM-1 and wave 2 do the same for phi
+  static_assert(2 * WARM <= T && 6 * WARM <= A_PAD && WARM % 64 == 0, "warm-up staging");
+  const long p0 = (long)ch0 * CHUNK;
+  const long p1 = (long)ch1 * CHUNK;  // first element right of the segment
+  const int cnt_th = sg != 0 ? WARM : 0;
+  const int cnt_ph = sg != S - 1 ? (int)min((long)WARM, N - p1) : 0;
+  {
+    float *wa = sh.u.in.a_s;
+    if (t < WARM) {
+      if (t < cnt_th) warm_stage<TIn>(a, b, c, cfg, p0 - WARM, +1, 0, wa, t);
+    } else if (t < 2 * WARM) {
+      if (t - WARM < cnt_ph) warm_stage<TIn>(a, b, c, cfg, p1 + cnt_ph - 1, -1, KO_PHI, wa + 3 * WARM, t - WARM);
+    }
+    __syncthreads();
+    Vec w0 = vec_start();
+    if (t < 64) {
+      if (cnt_th) w0 = warm_loop(wa, cnt_th);
+    } else if (t >= WARM && t < WARM + 64) {
+      if (cnt_ph) w0 = warm_loop(wa + 3 * WARM, cnt_ph);
+    }
+    if (t == 0) {
+      sh.carry[0][0] = w0;
+      sh.carry[1][0] = w0;
+      put_vec(info + 10, w0);
+    }
+    if (t == WARM) put_vec(info + 15, w0);
+  }
+  // theta over the segment
+  sweepA_range<TIn, true>(a, b, c, cfg, sh, ctx, st, ch0, ch1, seen, bad);
+  __syncthreads();
+  if (t == 0) put_vec(info + 0, sh.carry[1][ctx.cpar[1]]);
+  __syncthreads();
+
+  // phi over the segment (no outputs yet: only the state leaving it on the left); its start was recorded by
+  // thread WARM above
+  if (t == WARM) {
+    const Vec ph0 = get_vec(info + 15);
+    sh.carry[0][ctx.cpar[0]] = ph0;
+    sh.carry[1][ctx.cpar[1]] = ph0;
+  }
+  {
+    auto one = [&](auto full, auto tail, int ch) __attribute__((always_inline)) {
+      constexpr bool FULL = decltype(full)::value, TAIL = decltype(tail)::value;
+      const long base = (long)ch * CHUNK;
+      float2 al[E];
+      float kw[E + 1];
+      unsigned vmask;
+      __syncthreads();
+      stage_chunk<TIn, FULL>(a, b, c, base, cfg, sh);
+      __syncthreads();
+      fetch_elems(sh, base, T - 1 - t, cfg, al, kw, vmask);
+      float k2[E];
+      two_pass<true, true, TAIL, KO_PHI>(al, kw, vmask, k2, sh, ctx, bad);
+    };
+    int ch = ch1 - 1;
+    if (ch >= ch0 && ch == nch - 1) {
+      one(BoolC<false>{}, BoolC<true>{}, ch);
+      --ch;
+    }
+    const int interior_begin = max(ch0, 1);
+    for (; ch >= interior_begin; --ch) one(BoolC<true>{}, BoolC<false>{}, ch);
+    if (ch >= ch0 && ch == 0) one(BoolC<false>{}, BoolC<false>{}, 0);
+  }
+  const int any_bad = __syncthreads_or(bad ? 1 : 0);
+  if (t == 0) {
+    put_vec(info + 5, sh.carry[1][ctx.cpar[1]]);
+    info[23] = any_bad ? 1.0f : 0.0f;
+  }
+  if (state && seen) {
+    if (seen & 1u) __hip_atomic_store(&state[0], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen & 2u) __hip_atomic_store(&state[1], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+struct Scal {  // complex mantissa * 2^e
+  float2 m;
+  int e;
+};
+__device__ __forceinline__ void snorm(Scal &v) {
+  const int de = expo(amax2(v.m));
+  v.m = sc2(v.m, pow2_neg(de));
+  v.e += de;
+}
+
+__device__ __forceinline__ Scal smul(const Scal &p, const Scal &q) {
+  Scal r;
+  r.m = cmul(p.m, q.m);
+  r.e = p.e + q.e;
+  snorm(r);
+  return r;
+}
+__device__ __forceinline__ Scal sone() {
+  Scal r;
+  r.m = make_float2(1.f, 0.f);
+  r.e = 0;
+  return r;
+}
+template <bool UP>
+__device__ __forceinline__ Scal sshfl(const Scal &v, int d) {
+  Scal r;
+  r.m.x = UP ? __shfl_up(v.m.x, d) : __shfl_down(v.m.x, d);
+  r.m.y = UP ? __shfl_up(v.m.y, d) : __shfl_down(v.m.y, d);
+  r.e = UP ? __shfl_up(v.e, d) : __shfl_down(v.e, d);
+  return r;
+}
+
+constexpr int MAX_SEGMENTS = 1024;
+
+// One wave per row, one lane per segment (64 at a time): checks every boundary estimate against the neighbouring
+// segment's outgoing state, forms the running factors of theta (C_s, left to right) and phi (D_s, right to left)
+// as products of complex scalars with exponents (wave scans over shuffles), and writes each segment's epilogue
+// factor C_s D_s / theta_N.
+__global__ __launch_bounds__(64) void bk_split_combine_kernel(long B, long N, char *__restrict__ ws, int *state,
+                                                              int call_id, int S) {
+  __shared__ float cm[3][MAX_SEGMENTS];
+  const long row = blockIdx.x;
+  const int lane = threadIdx.x;
+  int *rowflag = reinterpret_cast<int *>(ws);
+  float *info = reinterpret_cast<float *>(ws + rowflag_bytes(B) + lane_state_bytes(B, N)) + row * S * SEG_INFO;
+  bool bad = false;
+  Scal carry = sone();
+  for (int g0 = 0; g0 < S; g0 += 64) {
+    const int sg = g0 + lane;
+    Scal q = sone();
+    if (sg < S) {
+      const float *me = info + sg * SEG_INFO;
+      bad |= me[23] != 0.0f;
+      if (sg > 0) {
+        const Vec out = get_vec(me - SEG_INFO + 0);  // theta leaving the segment on the left
+        const Vec est = get_vec(me + 10);
+        bad |= ratio_differs_tight(est, out);
+        q.m = cdiv(out.x0, est.x0);  // this segment's terms times the running product are the true ones
+        q.e = out.e;
+        snorm(q);
+      }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const Scal o = sshfl<true>(q, d);
+      if (lane >= d) q = smul(q, o);
+    }
+    const Scal C = smul(carry, q);
+    if (sg < S) {
+      cm[0][sg] = C.m.x;
+      cm[1][sg] = C.m.y;
+      cm[2][sg] = __int_as_float(C.e);
+    }
+    carry.m.x = __shfl(C.m.x, 63);
+    carry.m.y = __shfl(C.m.y, 63);
+    carry.e = __shfl(C.e, 63);
+  }
+  __syncthreads();
+  // theta_N = C_{S-1} * (theta leaving the last segment)
+  const Vec last = get_vec(info + (S - 1) * SEG_INFO);
+  Scal det;
+  det.m = cmul(carry.m, last.x0);
+  det.e = carry.e + last.e;
+  snorm(det);
+  carry = sone();
+  for (int g0 = ((S - 1) / 64) * 64; g0 >= 0; g0 -= 64) {
+    const int sg = g0 + lane;
+    Scal q = sone();
+    if (sg < S - 1) {
+      const float *me = info + sg * SEG_INFO;
+      const Vec out = get_vec(me + SEG_INFO + 5);  // phi leaving the segment on the right
+      const Vec est = get_vec(me + 15);
+      bad |= ratio_differs_tight(est, out);
+      q.m = cdiv(out.x0, est.x0);
+      q.e = out.e;
+      snorm(q);
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const Scal o = sshfl<false>(q, d);
+      if (lane + d < 64) q = smul(q, o);
+    }
+    const Scal D = smul(carry, q);
+    if (sg < S) {
+      Scal f;
+      f.m = cdiv(cmul(make_float2(cm[0][sg], cm[1][sg]), D.m), det.m);
+      f.e = __float_as_int(cm[2][sg]) + D.e - det.e;
+      snorm(f);
+      float *me = info + sg * SEG_INFO;
+      me[20] = f.m.x;
+      me[21] = f.m.y;
+      me[22] = __int_as_float(-f.e);
+    }
+    carry.m.x = __shfl(D.m.x, 0);
+    carry.m.y = __shfl(D.m.y, 0);
+    carry.e = __shfl(D.e, 0);
+  }
+  const int any_bad = __syncthreads_or(bad ? 1 : 0);
+  if (lane == 0) {
+    rowflag[row] = any_bad ? 1 : 0;
+    if (any_bad) __hip_atomic_store(&state[2], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <typename TIn, bool PHI_EXACT>
+__global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_split_output_kernel(
+    const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
+    const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, float2 *__restrict__ G_,
+    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, unsigned flags, int S, int seg_ch) {
+  __shared__ Shared sh;
+  const long row = blockIdx.x / S;
+  const int sg = blockIdx.x % S;
+  int *rowflag = reinterpret_cast<int *>(ws);
+  if (rowflag[row] != 0) return;  // the whole row is recomputed by the one-workgroup kernel
+  const TIn *a = a_ + row * lda;
+  const TIn *b = b_ + row * ldb;
+  const TIn *c = c_ + row * ldc;
+  float2 *G = G_ + row * N;
+  float2 *F = F_ ? F_ + row * N : nullptr;
+  const int nch = (int)((N + CHUNK - 1) / CHUNK);
+  const int ch0 = sg * seg_ch;
+  const int ch1 = min(nch, ch0 + seg_ch);
+  const float *st = reinterpret_cast<const float *>(ws + rowflag_bytes(B)) + row * (long)nch * 5 * T;
+  const float *info =
+      reinterpret_cast<const float *>(ws + rowflag_bytes(B) + lane_state_bytes(B, N)) + (row * S + sg) * SEG_INFO;
+  RowCfg cfg;
+  cfg.z = z_dev ? make_float2(z_dev[0], z_dev[1]) : make_float2(z_re, z_im);
+  cfg.N = N;
+  cfg.raw = (flags & BKCORE_FLAG_RAW) != 0;
+  cfg.fix_bc = false;
+  const int t = threadIdx.x;
+  ScanCtx ctx;
+  ctx.nscan = 0;
+  ctx.cpar[0] = 0;
+  ctx.cpar[1] = 0;
+  bool bad = false;
+  // uniform values, kept in scalar registers
+  const float2 factor = make_float2(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(info[20]))),
+                                    __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(info[21]))));
+  const int e_factor = __builtin_amdgcn_readfirstlane(__float_as_int(info[22]));
+  if (t == 0) {
+    const Vec ph0 = get_vec(info + 15);
+    sh.carry[0][0] = ph0;
+    sh.carry[1][0] = ph0;
+  }
+  constexpr int KO_PHI = PHI_EXACT ? 1 : 0;
+  sweepB_range<TIn, true, KO_PHI, false>(a, b, c, cfg, sh, ctx, st, ch0, ch1, factor, e_factor, G, F, nullptr, nullptr,
+                                         bad);
+  const int any_bad = __syncthreads_or(bad ? 1 : 0);
+  if (t == 0 && any_bad) {
+    atomicOr(&rowflag[row], 1);
+    __hip_atomic_store(&state[2], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -896,6 +1328,22 @@ int g_call_counter = 0;
 
 inline int chunks_of(int64_t N) { return (int)((N + CHUNK - 1) / CHUNK); }
 
+// How a (B, N) problem is cut: segments per row (1 = one workgroup per row) and chunks per segment.  Rows are cut
+// only when there are too few of them to occupy half of the 256 CUs and they are long enough (measured break-even:
+// about 140 rows).
+inline void split_plan(int64_t B, int64_t N, int &S, int &seg_ch) {
+  const int nch = chunks_of(N);
+  S = 1;
+  seg_ch = nch;
+  if (B > 128 || nch < 8) return;  // up to 256 rows run as one round of one workgroup per CU, which is faster
+  int want = (int)((1024 + B - 1) / B);  // segments per row that give about 1024 workgroups
+  if (want > nch / 2) want = nch / 2;     // at least two chunks per segment
+  if (want > MAX_SEGMENTS) want = MAX_SEGMENTS;
+  if (want < 2) return;
+  seg_ch = (nch + want - 1) / want;
+  S = (nch + seg_ch - 1) / seg_ch;
+}
+
 template <typename TIn, bool PHI_EXACT, bool SAVE>
 int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
                     const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
@@ -913,7 +1361,29 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
                      (const TIn *)a, (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re,   \
                      z_im, (long)B, (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id,     \
                      SECOND, flags, (float2 *)save_r, (float2 *)save_s)
-  if (state) {
+  int S = 1, seg_ch = 0;
+  if (state && !SAVE) split_plan(B, N, S, seg_ch);
+  if (S > 1) {
+    // few long rows: several workgroups per row, then the (normally empty) launch for rows whose checks failed
+    const unsigned grid = (unsigned)(B * S);
+    hipLaunchKernelGGL((bk_split_aggregate_kernel<TIn, PHI_EXACT>), dim3(grid), dim3(T), 0, stream, (const TIn *)a,
+                       (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re, z_im, (long)B,
+                       (long)N, (char *)ws, (int *)state, call_id, flags, S, seg_ch);
+    hipLaunchKernelGGL(bk_split_combine_kernel, dim3((unsigned)B), dim3(64), 0, stream, (long)B, (long)N,
+                       (char *)ws, (int *)state, call_id, S);
+    hipLaunchKernelGGL((bk_split_output_kernel<TIn, PHI_EXACT>), dim3(grid), dim3(T), 0, stream, (const TIn *)a,
+                       (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re, z_im, (long)B,
+                       (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id, flags, S, seg_ch);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess) {
+      BK_LAUNCH(false, 1);
+      err = hipGetLastError();
+    }
+    if (err != hipSuccess) {
+      g_last_hip_error = (int)err;
+      return BKCORE_ELAUNCH;
+    }
+  } else if (state) {
     // fast first launch, then the (normally empty) second launch for rows that need the two-scan path
     BK_LAUNCH(true, 0);
     hipError_t err = hipGetLastError();
@@ -955,7 +1425,10 @@ extern "C" {
 
 size_t bkcore_workspace_bytes(int64_t B, int64_t N) {
   if (B <= 0 || N <= 0) return 0;
-  return rowflag_bytes(B) + (size_t)B * (size_t)chunks_of(N) * 5 * T * sizeof(float);
+  int S = 1, seg_ch = 0;
+  split_plan(B, N, S, seg_ch);
+  const size_t seg_records = S > 1 ? (size_t)B * (size_t)S * SEG_INFO * sizeof(float) : 0;
+  return rowflag_bytes(B) + lane_state_bytes(B, N) + seg_records;
 }
 
 int bkcore_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc, int in_dtype,

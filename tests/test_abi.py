@@ -41,7 +41,7 @@ def test_host_side_argument_checks():
     assert L.bkcore_forward(None, 0, None, 0, None, 0, 0, None, 0.0, 1.0, 0, 16, None, None, None, 0, None, 0, None) == 0
     assert L.bkcore_forward(None, 0, None, 0, None, 0, 0, None, 0.0, 1.0, -1, 16, None, None, None, 0, None, 0, None) == -1
     assert L.bkcore_workspace_bytes(1024, 32768) == 1024 * 4 + 1024 * 8 * 5 * 256 * 4
-    assert L.bkcore_workspace_bytes(16, 1 << 20) == 256 + 16 * 256 * 5 * 256 * 4
+    assert L.bkcore_workspace_bytes(16, 1 << 20) == 256 + 16 * 256 * 5 * 256 * 4 + 16 * 64 * 32 * 4  # + segment records
     assert L.bkcore_workspace_bytes(0, 128) == 0
     # a problem that needs scratch is refused without it (checked before any launch)
     one = ctypes.c_void_p(16)
