@@ -186,6 +186,22 @@ def main():
             "bwd_GBps": BWD_BYTES * elems / t_bwd / 1e9,
             "hbm_frac_fwd_bwd": (FWD_BYTES + BWD_BYTES) * elems / (t_fwd + t_bwd) / HBM_PEAK,
         }
+        if world == 1:
+            # secondary measurements (not part of `value`): analytic-mode backward at the same size, and the
+            # long-context configuration BASELINE.json configs[2] (B=16, N=2^20: several workgroups per row)
+            with torch.no_grad():
+                t_ana = timed(lambda: bkcore.bk_backward_analytic(ad, b, c, z, gfeat, None), 5)
+                a3, b3, c3, z3, g3 = make_inputs(16, 1 << 20, device, 99)
+                a3 = a3.detach()
+                G3 = bkcore.bk_forward(a3, b3, c3, z3)[1]
+                t3f = timed(lambda: bkcore.bk_forward(a3, b3, c3, z3), reps)
+                t3b = timed(lambda: bkcore.bk_backward_reference(G3, g3, None, 0.5), reps)
+            out["secondary"] = {
+                "analytic_backward_ms": t_ana * 1e3,
+                "analytic_backward_note": "grad for he_diag, h0_super, h0_sub; re-runs the forward inside",
+                "long_context_B16_N1048576": {"fwd_ms": t3f * 1e3, "bwd_ms": t3b * 1e3,
+                                              "diag_elems_per_sec": 16 * (1 << 20) / (t3f + t3b)},
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N)
             out["cpu_baseline_reference_cost_model"] = cpu_baseline_torch_loop()

@@ -249,6 +249,7 @@ class BKCoreFunction(torch.autograd.Function):
     USE_PARALLEL_SCAN = True
     PHI_K_INDEX = "reference"
     GRAD_MODE = "reference"
+    WARN_NONFINITE_GRAD = False     # True: check the incoming gradient on the host and warn as bk_core.py:321-325 does
 
     @staticmethod
     def forward(ctx, he_diag, h0_super, h0_sub, z, use_triton=None, use_parallel_scan=None):
@@ -279,6 +280,13 @@ class BKCoreFunction(torch.autograd.Function):
     def backward(ctx, grad_output_features, grad_G_ii):
         if grad_output_features is None and grad_G_ii is None:
             return None, None, None, None, None, None
+        # NaN / Inf in the incoming gradient count as 0 / +-max inside the kernels (torch.nan_to_num semantics,
+        # bk_core.py:325); the reference also warns, which costs a host synchronisation, so that is opt-in
+        if BKCoreFunction.WARN_NONFINITE_GRAD and grad_output_features is not None \
+                and not torch.isfinite(grad_output_features).all():
+            msg = "BKCoreFunction backward: Incoming 'grad_output_features' contains NaN or Inf."
+            warnings.warn(msg, RuntimeWarning)
+            logger.warning(msg)
         if ctx.bk_mode == "analytic":
             a, b, c = ctx.saved_tensors
             n = a.shape[-1]

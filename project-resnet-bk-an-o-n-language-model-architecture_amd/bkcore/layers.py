@@ -1,0 +1,90 @@
+"""nn.Module call sites of BK-Core, mirrored so that a user of the reference finds the same constructor and
+forward signatures on top of the HIP operator.
+
+  * ``BKCoreLayer``           the BK-Core branch of ``MoEResNetBKLayer`` (reference src/models/resnet_bk.py:84-176,
+                              216-219): v_proj -> tanh saturation -> he_diag -> BKCoreFunction (bf16 operands, complex64
+                              device z, expand()ed off-diagonal buffers) -> clamp -> output_proj * bk_scale.  Parameter
+                              and buffer names are the reference's, so its state_dict entries load unchanged.  The
+                              FFN / MoE / attention branches of that layer are not part of this package.
+  * ``CUDAOptimizedBKCore``   same constructor and ``forward(v) -> (B, N, 2)`` as the reference module of that name
+                              (src/models/cuda_bk_core.py:243-413).  The reference class evaluates the un-regularised
+                              recurrence in its own CUDA kernels and clamps Re/Im to +-10; here the numbers come from
+                              the HIP operator (regularised, soft-clamped: the semantics of bk_core.py) followed by the
+                              same +-10 clamp, so results agree to the regularisation's 1e-3 on well-conditioned input.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .bk_core import BKCoreFunction
+
+
+class BKCoreLayer(nn.Module):
+    def __init__(self, d_model: int, n_seq: int, v_max: float = 5.0, feature_clamp: float | None = 5.0):
+        super().__init__()
+        self.d_model = d_model
+        self.n_seq = n_seq
+        self.v_proj = nn.Linear(d_model, 1)
+        self.output_proj = nn.Linear(2, d_model)
+        self.bk_scale = nn.Parameter(torch.ones(d_model, dtype=torch.float32))
+        self.gamma = nn.Parameter(torch.tensor(0.0, dtype=torch.float32))
+        self.epsilon_param = nn.Parameter(torch.tensor(1.0, dtype=torch.float32))
+        with torch.no_grad():                                   # resnet_bk.py:92-95
+            nn.init.normal_(self.v_proj.weight, mean=0.0, std=1e-4)
+            nn.init.zeros_(self.v_proj.bias)
+        # identity start: diagonal 1, off-diagonals 0 (resnet_bk.py:124-126)
+        self.register_buffer("h0_diag_base", torch.full((1, n_seq), 1.0, dtype=torch.float32))
+        self.register_buffer("h0_sub_base", torch.zeros((1, n_seq - 1), dtype=torch.float32))
+        self.register_buffer("h0_super_base", torch.zeros((1, n_seq - 1), dtype=torch.float32))
+        self.v_max = v_max
+        self.feature_clamp = feature_clamp
+        self.bk_core = BKCoreFunction.apply
+        self.last_g_ii = None
+
+    def spectral_features(self, x: torch.Tensor):
+        """x (B, N, D) -> (features (B, N, 2) float32, G_ii (B, N, 1) complex64)."""
+        B, N, _ = x.shape
+        if N != self.n_seq:
+            raise ValueError(f"Sequence length mismatch: expected {self.n_seq}, got {N}")
+        v = self.v_proj(x).squeeze(-1)
+        v = torch.nan_to_num(v, nan=0.0, posinf=self.v_max, neginf=-self.v_max)
+        v = self.v_max * torch.tanh(v / self.v_max)
+        he_diag = self.h0_diag_base.expand(B, -1) + v
+        epsilon = F.softplus(self.epsilon_param) + 1e-4
+        z = (1.0j * epsilon + 1j * self.gamma).to(dtype=torch.complex64, device=he_diag.device)
+        features, g = self.bk_core(he_diag.to(torch.bfloat16),
+                                   self.h0_super_base.expand(B, -1).to(torch.bfloat16),
+                                   self.h0_sub_base.expand(B, -1).to(torch.bfloat16), z)
+        G_ii = g.unsqueeze(-1)
+        bad = torch.isnan(G_ii.real) | torch.isnan(G_ii.imag)
+        G_ii = torch.where(bad, torch.ones_like(G_ii), G_ii)    # no host sync: the replacement is unconditional
+        self.last_g_ii = G_ii
+        return features, G_ii
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """The layer's spectral branch: bk_scale * output_proj(clamp(features)) (resnet_bk.py:216-219)."""
+        features, _ = self.spectral_features(x)
+        if self.feature_clamp is not None:
+            features = torch.clamp(features, -self.feature_clamp, self.feature_clamp)
+        return self.bk_scale * self.output_proj(features)
+
+
+class CUDAOptimizedBKCore(nn.Module):
+    def __init__(self, n_seq: int, use_cuda_kernels: bool = True):
+        super().__init__()
+        self.n_seq = n_seq
+        self.use_cuda_kernels = use_cuda_kernels                # kept; the HIP kernels are the only back-end
+        self.cuda_available = True
+        self.register_buffer("h0_diag", torch.full((n_seq,), -2.0))
+        self.register_buffer("h0_sub", torch.full((n_seq - 1,), 1.0))
+        self.register_buffer("h0_super", torch.full((n_seq - 1,), 1.0))
+        self.z = torch.tensor(1.0j, dtype=torch.complex128)
+
+    def forward(self, v: torch.Tensor) -> torch.Tensor:
+        B, N = v.shape
+        he_diag = self.h0_diag.unsqueeze(0).expand(B, -1) + v
+        features, _ = BKCoreFunction.apply(he_diag.float(), self.h0_super.unsqueeze(0).expand(B, -1),
+                                           self.h0_sub.unsqueeze(0).expand(B, -1), complex(self.z))
+        return torch.clamp(features, -10.0, 10.0)
