@@ -160,11 +160,12 @@ __device__ __forceinline__ float soft_g(float d) {
 __device__ __forceinline__ void ratio_terms(float2 r, float2 &inv, float2 &w, float &tau) {
   const float n = fmaf(r.x, r.x, r.y * r.y);
   const float lnr = 0.5f * __logf(n);
-  const float ex = __expf(soft_g(-lnr));
+  const float gd = soft_g(-lnr);
+  const float ex = __expf(gd);
   const float rn = 1.0f / n;
   inv = make_float2(r.x * rn, -r.y * rn);
   w = make_float2(inv.x * ex, inv.y * ex);
-  const float th = tanhf(lnr * (1.0f / 88.0f));
+  const float th = (gd - lnr) * (1.0f / 88.0f);  // tanh(-ln|r| / 88) = (g(d) + d) / 88
   tau = th * th;
 }
 
@@ -189,23 +190,14 @@ __device__ __forceinline__ float2 cot_q(float2 Graw, float2 gbar) {
   const float m2 = fmaf(Graw.x, Graw.x, Graw.y * Graw.y);
   if (!(m2 > 0.0f)) return make_float2(0.f, 0.f);  // zeroed by the forward (not finite, or out of range)
   const float L = 0.5f * __logf(m2);
-  const float F = __expf(soft_g(L));
+  const float gL = soft_g(L);
+  const float F = __expf(gL);
   const float2 Gc = make_float2(Graw.x * F, Graw.y * F);
   const float2 X = make_float2(fmaf(gbar.x, Gc.x, gbar.y * Gc.y), fmaf(gbar.x, Gc.y, -gbar.y * Gc.x));  // conj(gbar) Gc
   const float mc2 = m2 * F * F;
   if (mc2 > 2500.0f) return make_float2(0.0f, X.y * 50.0f * rsqrtf(mc2));  // clipped: only the phase moves
-  const float th = tanhf(L * (1.0f / 88.0f));
+  const float th = (gL + L) * (1.0f / 88.0f);  // tanh(L / 88)
   return make_float2(X.x - th * th * X.x, X.y);
-}
-
-__device__ __forceinline__ float2 load_gbar(const float2 *gf, const float2 *gG, long i) {
-  float2 g = make_float2(0.f, 0.f);
-  if (gf) g = gf[i];
-  if (gG) { const float2 q = gG[i]; g.x += q.x; g.y += q.y; }
-  // a cotangent that is not a number counts as 0, as in the reference's backward (bk_core.py:321-325)
-  if (!(fabsf(g.x) <= 3.0e38f)) g.x = 0.f;
-  if (!(fabsf(g.y) <= 3.0e38f)) g.y = 0.f;
-  return g;
 }
 
 // Re(x D),  D = d reg(a - z)/d a,  reg(x) = x (1 + 1e-3/|x|)
@@ -221,20 +213,67 @@ __device__ __forceinline__ float times_dreg(float2 x, float a, float2 z) {
 
 __device__ __forceinline__ float finite_or_zero(float v) { return fabsf(v) <= 3.0e38f ? v : 0.0f; }
 
+// ---- per-lane block I/O ----------------------------------------------------------------------------------------
+// A lane owns EB consecutive elements.  When the whole block lies inside the row it is moved with 16-byte accesses
+// (the struct is only 4-byte aligned: rows of N or N-1 elements start anywhere); otherwise element by element with
+// `fill` for the positions outside [lo, hi).
+struct __attribute__((aligned(4))) F4u {
+  float v[4];
+};
+template <int NF>
+__device__ __forceinline__ void load_block(const float *__restrict__ p, long first, long lo, long hi, float fill,
+                                           float (&out)[NF]) {
+  static_assert(NF % 4 == 0, "whole 16-byte pieces");
+  if (first >= lo && first + NF <= hi) {
+#pragma unroll
+    for (int q = 0; q < NF / 4; ++q) {
+      const F4u t = *reinterpret_cast<const F4u *>(p + first + 4 * q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[4 * q + r] = t.v[r];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < NF; ++e) {
+      const long j = first + e;
+      out[e] = (j >= lo && j < hi) ? p[j] : fill;
+    }
+  }
+}
+template <int NF>
+__device__ __forceinline__ void store_block(float *__restrict__ p, long first, long lo, long hi,
+                                            const float (&in)[NF]) {
+  if (first >= lo && first + NF <= hi) {
+#pragma unroll
+    for (int q = 0; q < NF / 4; ++q) {
+      F4u t;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t.v[r] = in[4 * q + r];
+      *reinterpret_cast<F4u *>(p + first + 4 * q) = t;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < NF; ++e) {
+      const long j = first + e;
+      if (j >= lo && j < hi) p[j] = in[e];
+    }
+  }
+}
+
 // ---- left -> right ------------------------------------------------------------------------------------------------
 template <int OFF>  // kphi_m = k_{m-OFF}
 __global__ __launch_bounds__(T) void bk_adjoint_phi_kernel(
     const float *__restrict__ a_, long lda, const float *__restrict__ b_, long ldb, const float *__restrict__ c_,
-    long ldc, const float *__restrict__ z_dev, float z_re, float z_im, long N, const float2 *__restrict__ Graw_,
-    const float2 *__restrict__ gf_, const float2 *__restrict__ gG_, const float2 *__restrict__ s_,
-    float2 *__restrict__ P_, float *__restrict__ ga_, float *__restrict__ gk_) {
+    long ldc, const float *__restrict__ z_dev, float z_re, float z_im, long N, const float *__restrict__ Graw_,
+    const float *__restrict__ gf_, const float *__restrict__ gG_, const float *__restrict__ s_,
+    float *__restrict__ P_, float *__restrict__ ga_, float *__restrict__ gk_) {
   __shared__ SharedAff sha;
   __shared__ SharedSum shs;
   const long row = blockIdx.x;
   const float *a = a_ + row * lda, *b = b_ + row * ldb, *c = c_ + row * ldc;
-  const float2 *Graw = Graw_ + row * N, *gf = gf_ ? gf_ + row * N : nullptr, *gG = gG_ ? gG_ + row * N : nullptr;
-  const float2 *sv = s_ + row * N;
-  float2 *P = P_ + row * N;
+  const float *Graw = Graw_ + row * N * 2;
+  const float *gf = gf_ ? gf_ + row * N * 2 : nullptr, *gG = gG_ ? gG_ + row * N * 2 : nullptr;
+  const float *sv = s_ + row * N * 2;
+  float *P = P_ + row * N * 2;
   float *ga = ga_ + row * N;
   float *gk = gk_ ? gk_ + row * (N - 1) : nullptr;
   const float2 z = z_dev ? make_float2(z_dev[0], z_dev[1]) : make_float2(z_re, z_im);
@@ -248,16 +287,40 @@ __global__ __launch_bounds__(T) void bk_adjoint_phi_kernel(
   __syncthreads();
   for (int ch = 0; ch < nch; ++ch) {
     const long first = (long)ch * CHUNK + (long)t * EB;
-    float2 q[EB];
+    float q[2 * EB];
+    {
+      float Gv[2 * EB], gv[2 * EB];
+      load_block<2 * EB>(Graw, 2 * first, 0, 2 * N, 0.0f, Gv);
+      if (gf) {
+        load_block<2 * EB>(gf, 2 * first, 0, 2 * N, 0.0f, gv);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 2 * EB; ++e) gv[e] = 0.0f;
+      }
+      if (gG) {
+        float hv[2 * EB];
+        load_block<2 * EB>(gG, 2 * first, 0, 2 * N, 0.0f, hv);
+#pragma unroll
+        for (int e = 0; e < 2 * EB; ++e) gv[e] += hv[e];
+      }
+#pragma unroll
+      for (int e = 0; e < EB; ++e) {
+        // a cotangent that is not a number counts as 0, as in the reference's backward (bk_core.py:321-325)
+        const float gx = fabsf(gv[2 * e]) <= 3.0e38f ? gv[2 * e] : 0.0f;
+        const float gy = fabsf(gv[2 * e + 1]) <= 3.0e38f ? gv[2 * e + 1] : 0.0f;
+        const float2 qq = cot_q(make_float2(Gv[2 * e], Gv[2 * e + 1]), make_float2(gx, gy));  // 0 for G_raw = 0
+        q[2 * e] = qq.x;
+        q[2 * e + 1] = qq.y;
+      }
+    }
     float2 sum = make_float2(0.f, 0.f);
 #pragma unroll
-    for (int e = 0; e < EB; ++e) {
-      const long j = first + e;
-      q[e] = make_float2(0.f, 0.f);
-      if (j < N) q[e] = cot_q(Graw[j], load_gbar(gf, gG, j));
-      sum = cadd(sum, q[e]);
-    }
+    for (int e = 0; e < EB; ++e) sum = cadd(sum, make_float2(q[2 * e], q[2 * e + 1]));
     float2 Prun = block_exclusive_sum(sum, shs, nsum);  // P_{first-1}
+    float sbuf[2 * EB], bk[EB], ck[EB];
+    load_block<2 * EB>(sv, 2 * first, 0, 2 * N, 1.0f, sbuf);
+    load_block<EB>(b, first - 1 - OFF, 0, N - 1, 0.0f, bk);  // k index of element j is j - 1 - OFF
+    load_block<EB>(c, first - 1 - OFF, 0, N - 1, 0.0f, ck);
     Aff st[EB];
     float2 wv[EB];
     Aff A = aff_identity();
@@ -269,26 +332,31 @@ __global__ __launch_bounds__(T) void bk_adjoint_phi_kernel(
       if (j >= 1 && j < N) {
         float2 inv;
         float tau;
-        ratio_terms(sv[j], inv, wv[e], tau);
-        const long ki = j - 1 - OFF;
-        const float kk = ki >= 0 ? b[ki] * c[ki] : 0.0f;
-        st[e] = step_map(kk, wv[e], tau, inv, Prun);  // c0 = P_{j-1}
+        ratio_terms(make_float2(sbuf[2 * e], sbuf[2 * e + 1]), inv, wv[e], tau);
+        st[e] = step_map(bk[e] * ck[e], wv[e], tau, inv, Prun);  // c0 = P_{j-1}
       }
-      Prun = cadd(Prun, q[e]);
-      if (j < N) P[j] = Prun;
+      Prun = cadd(Prun, make_float2(q[2 * e], q[2 * e + 1]));
+      q[2 * e] = Prun.x;  // q now holds P_j
+      q[2 * e + 1] = Prun.y;
       A = compose(st[e], A);
     }
+    store_block<2 * EB>(P, 2 * first, 0, 2 * N, q);
     float2 x = block_exclusive_aff(A, sha, naff);  // mu_{first-1} / s_{first-1}
+    float av[EB], gav[EB], gkv[EB];
+    load_block<EB>(a, first, 0, N, 0.0f, av);
 #pragma unroll
     for (int e = 0; e < EB; ++e) {
       const long j = first + e;
+      gkv[e] = -fmaf(x.x, wv[e].x, -x.y * wv[e].y);
+      gav[e] = 0.0f;
       if (j < N) {
-        const long ki = j - 1 - OFF;
-        if (gk && j >= 1 && ki >= 0) gk[ki] = -fmaf(x.x, wv[e].x, -x.y * wv[e].y);
         x = apply(st[e], x);
-        ga[j] = j >= 1 ? times_dreg(x, a[j], z) : 0.0f;
+        if (j >= 1) gav[e] = times_dreg(x, av[e], z);
       }
     }
+    store_block<EB>(ga, first, 0, N, gav);
+    // element j >= 1 wrote the phi part of grad_k at index j - 1 - OFF (0 from j = 1: mu_0 = 0)
+    if (gk) store_block<EB>(gk, first - 1 - OFF, 0, N - 1 - OFF, gkv);
   }
 }
 
@@ -296,12 +364,12 @@ __global__ __launch_bounds__(T) void bk_adjoint_phi_kernel(
 template <int OFF>
 __global__ __launch_bounds__(T) void bk_adjoint_theta_kernel(
     const float *__restrict__ a_, long lda, const float *__restrict__ b_, long ldb, const float *__restrict__ c_,
-    long ldc, const float *__restrict__ z_dev, float z_re, float z_im, long N, const float2 *__restrict__ r_,
-    const float2 *__restrict__ P_, float *__restrict__ ga_, float *__restrict__ gb_, float *__restrict__ gc_) {
+    long ldc, const float *__restrict__ z_dev, float z_re, float z_im, long N, const float *__restrict__ r_,
+    const float *__restrict__ P_, float *__restrict__ ga_, float *__restrict__ gb_, float *__restrict__ gc_) {
   __shared__ SharedAff sha;
   const long row = blockIdx.x;
   const float *a = a_ + row * lda, *b = b_ + row * ldb, *c = c_ + row * ldc;
-  const float2 *rv = r_ + row * N, *P = P_ + row * N;
+  const float *rv = r_ + row * N * 2, *P = P_ + row * N * 2;
   float *ga = ga_ + row * N;
   float *gb = gb_ ? gb_ + row * (N - 1) : nullptr;
   float *gc = gc_ ? gc_ + row * (N - 1) : nullptr;
@@ -313,6 +381,11 @@ __global__ __launch_bounds__(T) void bk_adjoint_theta_kernel(
   __syncthreads();
   for (int ch = nch - 1; ch >= 0; --ch) {
     const long first = (long)ch * CHUNK + (long)(T - 1 - t) * EB;  // descending segments over ascending threads
+    float rbuf[2 * EB], pbuf[2 * EB], bk[EB], ck[EB];
+    load_block<2 * EB>(rv, 2 * first, 0, 2 * N, 1.0f, rbuf);
+    load_block<2 * EB>(P, 2 * first, 0, 2 * N, 0.0f, pbuf);
+    load_block<EB>(b, first, 0, N - 1, 0.0f, bk);
+    load_block<EB>(c, first, 0, N - 1, 0.0f, ck);
     Aff st[EB];
     float2 wv[EB];
     Aff A = aff_identity();
@@ -325,28 +398,35 @@ __global__ __launch_bounds__(T) void bk_adjoint_theta_kernel(
       if (j < N) {
         float2 inv;
         float tau;
-        ratio_terms(rv[j], inv, wv[e], tau);
-        const float kk = j < N - 1 ? b[j] * c[j] : 0.0f;
-        const float2 Pj = P[j];
-        st[e] = step_map(kk, wv[e], tau, inv, make_float2(-Pj.x, -Pj.y));
+        ratio_terms(make_float2(rbuf[2 * e], rbuf[2 * e + 1]), inv, wv[e], tau);
+        st[e] = step_map(bk[e] * ck[e], wv[e], tau, inv, make_float2(-pbuf[2 * e], -pbuf[2 * e + 1]));
       }
       A = compose(st[e], A);
     }
     float2 x = block_exclusive_aff(A, sha, naff);  // lam_{j+1} / r_{j+1} for the lane's last element j
+    float av[EB], gav[EB], gkp[EB], gbv[EB], gcv[EB];
+    load_block<EB>(a, first, 0, N, 0.0f, av);
+    load_block<EB>(ga, first, 0, N, 0.0f, gav);
+    if (gb) {
+      load_block<EB>(gb, first, 0, N - 1 - OFF, 0.0f, gkp);  // the phi part of grad_k, left there by the phi kernel
+    } else {
+#pragma unroll
+      for (int e = 0; e < EB; ++e) gkp[e] = 0.0f;
+    }
 #pragma unroll
     for (int qi = 0; qi < EB; ++qi) {
       const int e = EB - 1 - qi;
       const long j = first + e;
-      if (j < N) {
-        const float gk_theta = -fmaf(x.x, wv[e].x, -x.y * wv[e].y);
-        x = apply(st[e], x);
-        ga[j] = finite_or_zero(ga[j] + times_dreg(x, a[j], z));
-        if (gb && j < N - 1) {
-          const float gk = gk_theta + (j + OFF <= N - 2 ? gb[j] : 0.0f);  // gb held the phi part of grad_k
-          gb[j] = finite_or_zero(c[j] * gk);
-          gc[j] = finite_or_zero(b[j] * gk);
-        }
-      }
+      const float gk = gkp[e] - fmaf(x.x, wv[e].x, -x.y * wv[e].y);
+      if (j < N) x = apply(st[e], x);
+      gav[e] = finite_or_zero(gav[e] + times_dreg(x, av[e], z));
+      gbv[e] = finite_or_zero(ck[e] * gk);
+      gcv[e] = finite_or_zero(bk[e] * gk);
+    }
+    store_block<EB>(ga, first, 0, N, gav);
+    if (gb) {
+      store_block<EB>(gb, first, 0, N - 1, gbv);
+      store_block<EB>(gc, first, 0, N - 1, gcv);
     }
   }
 }
@@ -388,15 +468,14 @@ int bkcore_backward_analytic(const float *a, int64_t lda, const float *b, int64_
                                               stream, sr, ss);
   if (rc != BKCORE_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const float2 *gf = (const float2 *)grad_features, *gg = (const float2 *)grad_G;
   float *gk = N > 1 ? grad_b : nullptr;
   float *gc = N > 1 ? grad_c : nullptr;
 #define BK_LAUNCH_ADJ(OFF)                                                                                            \
   hipLaunchKernelGGL((bk_adjoint_phi_kernel<OFF>), dim3((unsigned)B), dim3(T), 0, s, a, (long)lda, b, (long)ldb, c,  \
-                     (long)ldc, z_dev, z_re, z_im, (long)N, (const float2 *)Graw, gf, gg, (const float2 *)ss,         \
-                     (float2 *)Pp, grad_a, gk);                                                                       \
+                     (long)ldc, z_dev, z_re, z_im, (long)N, (const float *)Graw, grad_features, grad_G,               \
+                     (const float *)ss, Pp, grad_a, gk);                                                              \
   hipLaunchKernelGGL((bk_adjoint_theta_kernel<OFF>), dim3((unsigned)B), dim3(T), 0, s, a, (long)lda, b, (long)ldb,   \
-                     c, (long)ldc, z_dev, z_re, z_im, (long)N, (const float2 *)sr, (const float2 *)Pp, grad_a, gk, gc)
+                     c, (long)ldc, z_dev, z_re, z_im, (long)N, (const float *)sr, (const float *)Pp, grad_a, gk, gc)
   if (flags & BKCORE_FLAG_PHI_EXACT) {
     BK_LAUNCH_ADJ(0);
   } else {
