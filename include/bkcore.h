@@ -36,6 +36,9 @@ extern "C" {
 #define BKCORE_FLAG_PHI_EXACT 2u  /* phi recurrence uses k_{i+1} (true trailing minors) instead of the
                                      reference's k_i (src/models/bk_core.py:165-171) */
 
+#define BKCORE_FLAG_SCAN_PATH 4u  /* diagnostics: take the scan-based first launch instead of the ratio-form one
+                                     (same results within the tolerance; see bkcore_forward) */
+
 /* error codes */
 #define BKCORE_OK 0
 #define BKCORE_EINVAL (-1)   /* bad argument (null pointer, negative size, unknown dtype) */

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libbkcore.so")
 F32, BF16, F16, F64 = 0, 1, 2, 3
 FLAG_RAW = 1
 FLAG_PHI_EXACT = 2
+FLAG_SCAN_PATH = 4
 STATE_BYTES = 64
 ABI_VERSION = 4
 EINVAL, ETOOLONG, ELAUNCH, EWORKSPACE = -1, -2, -3, -4

@@ -26,7 +26,7 @@ from . import _lib
 logger = logging.getLogger(__name__)
 
 _DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16, torch.float64: _lib.F64}
-_DEBUG = {"keep_ws": False, "last_ws": None, "last_B": 0}  # diagnostics: see rows_recomputed()
+_DEBUG = {"keep_ws": False, "last_ws": None, "last_B": 0, "scan_path": False}  # diagnostics: see rows_recomputed()
 _state = {}  # (device index, stream handle) -> persistent int32 state block for the NaN-sanitiser corner
 
 
@@ -106,7 +106,8 @@ def bk_forward(a, b, c, z, raw: bool = False, phi_exact: bool = False, want_feat
         stream = torch.cuda.current_stream().cuda_stream
         zkeep, pz, zre, zim = _prep_z(z, a.device)
         state = _state_block(a.device, stream)
-        flags = (_lib.FLAG_RAW if raw else 0) | (_lib.FLAG_PHI_EXACT if phi_exact else 0)
+        flags = (_lib.FLAG_RAW if raw else 0) | (_lib.FLAG_PHI_EXACT if phi_exact else 0) \
+            | (_lib.FLAG_SCAN_PATH if _DEBUG["scan_path"] else 0)
         ws_bytes = int(L.bkcore_workspace_bytes(B, N))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
         rc = L.bkcore_forward(pa, lda, pb if nb else None, ldb, pc if nb else None, ldc, dt, pz, zre, zim, B, N,

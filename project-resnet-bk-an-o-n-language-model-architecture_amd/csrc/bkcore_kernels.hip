@@ -1256,6 +1256,376 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_split_output_kernel(
   }
 }
 
+// ---- single-sweep forward in ratio form ------------------------------------------------------------------------
+// The same numbers from a different evaluation order.  With r_i = theta_{i+1}/theta_i and s_m = phi_m/phi_{m+1} the
+// reference's recurrences (bk_core.py:120-184) read
+//     r_i = a'_i - k_{i-1} om(r_{i-1}),   s_m = a'_m - kphi_m om(s_{m+1}),   om(r) = exp(g(-ln|r|)) / r
+// (g(d) = 88 tanh(d/88) - d is the in-recurrence soft clamp relative to the exact recurrence), and
+//     G_raw,j = theta_j phi_{j+1} / theta_N = (1/r_j) prod_{m>j} s_m / r_m .
+// Wherever these first-order maps contract (|k| < |r|^2: every well-conditioned row) a ratio forgets where it started
+// within a few steps, so a lane does not need a scan to know the ratio entering its 16 elements: it runs the map over
+// the 16 elements before them (after them, for s) from the start value.  The estimate is verified: the lane that owns
+// those 16 elements ran the same steps from its own, different, start; both ends must agree to 2e-6.  A row with any
+// disagreement is flagged and recomputed by the scan kernel in the second launch, exactly like the scan fast path.
+// What still needs a scan is the product over m > j -- of complex scalars, carried as mantissa x 2^e, one scan per
+// chunk -- and the only state carried from chunk to chunk is that running product, so the row is read ONCE
+// (chunks right -> left): 12 bytes in, 16 out per element, no lane states.
+#ifndef BK_RATIO_WAVES
+#define BK_RATIO_WAVES 2
+#endif
+constexpr int RH = 16;                          // warm-up length = halo staged on both sides of a chunk
+constexpr int RN = CHUNK + 2 * RH;              // staged elements per chunk
+constexpr int RAL_PAD = RN + RN / 16 + 8;       // float2 entries, index q + q/16
+constexpr int RK_PAD = RN + 1 + (RN + 1) / 16 + 8;
+
+struct Prod {  // complex mantissa * 2^e
+  float2 m;
+  int e;
+};
+__device__ __forceinline__ Prod prod_one() {
+  Prod p;
+  p.m = make_float2(1.f, 0.f);
+  p.e = 0;
+  return p;
+}
+__device__ __forceinline__ void pnorm(Prod &p) {
+  const int de = expo(amax2(p.m));
+  p.m = sc2(p.m, pow2_neg(de));
+  p.e += de;
+}
+__device__ __forceinline__ Prod pmul(const Prod &a, const Prod &b) {
+  Prod r;
+  r.m = cmul(a.m, b.m);
+  r.e = a.e + b.e;
+  pnorm(r);
+  return r;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Prod prod_dpp(const Prod &p) {  // identity where the selection has no source lane
+  Prod r;
+  r.m.x = dpp_f<CTRL, ROW_MASK>(1.0f, p.m.x);
+  r.m.y = dpp_f<CTRL, ROW_MASK>(0.0f, p.m.y);
+  r.e = dpp_i<CTRL, ROW_MASK>(0, p.e);
+  return r;
+}
+
+struct SharedR {
+  union {
+    struct {
+      float2 al_s[RAL_PAD];  // regularised diagonal a' of elements base - RH .. base + CHUNK + RH - 1
+      float k_s[RK_PAD];     // k_{i-1} for the same elements, plus one more
+    } in;
+    float2 out_s[O_PAD];     // G of one chunk for coalesced stores
+  } u;
+  float4 wedge[2][WAVES];    // last lane of each wave: theta warm-up result (xy) and phi end value (zw), for the
+                             // first lane of the next wave
+  float4 edge[2];            // the same from the first lane of the chunk to the right
+  Prod tot[2][WAVES];
+  Prod carry[2];
+};
+
+__device__ __forceinline__ int rpad16(int q) { return q + (q >> 4); }
+// staged slot q0 + d of a lane whose first slot q0 is a multiple of 16: base + roff(d), d a compile-time constant
+__device__ __forceinline__ constexpr int roff(int d) { return d + (d >= 0 ? d / 16 : -((15 - d) / 16)); }
+
+// One step of either ratio map: r = al - k * om_prev; returns om(r) and hands back r and 1/r.  The reciprocal of
+// |r|^2 is refined by one Newton step and the clamp factor exp(g) is an exp2 of a tiny argument: the hardware log
+// and exp2 round with a bias of a fraction of an ulp, which is harmless inside the contracting recurrence and in g,
+// but would add up linearly over the N factors of the product if 1/|r|^2 were formed as exp2(-log2 |r|^2).
+__device__ __forceinline__ float2 ratio_step(float2 al, float k, float2 om, float2 &r, float2 &inv) {
+  r = make_float2(fmaf(-k, om.x, al.x), fmaf(-k, om.y, al.y));
+  const float n = fmaf(r.x, r.x, r.y * r.y);
+  float y = __builtin_amdgcn_rcpf(n);
+  y = fmaf(y, fmaf(-n, y, 1.0f), y);
+  inv = make_float2(r.x * y, -r.y * y);
+  // clamp factor exp(g(d)), d = -ln|r| = -(ln 2 / 2) log2 |r|^2, |d| limited to 22.  g = -88 (u^3/3 - 2u^5/15 +
+  // 17u^7/315), u = d/88 (|u| <= 1/4: relative error of g below 2e-5); exp(g) by its series to g^3 (|g| <= 0.02 for
+  // any |r| between 1e-3 and 1e9; the clamp is a 1e-5 effect, so 1e-3 of it is far below float32 resolution).
+  const float u = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(n) * (-LN2_HALF / 88.0f), -0.25f, 0.25f);
+  const float s2 = u * u;
+  float p = fmaf(s2, -88.0f * 17.0f / 315.0f, 88.0f * 2.0f / 15.0f);
+  p = fmaf(s2, p, -88.0f / 3.0f);
+  const float g = (u * s2) * p;
+  const float wc = fmaf(g, fmaf(g, fmaf(g, 1.0f / 6.0f, 0.5f), 1.0f), 1.0f);
+  return make_float2(inv.x * wc, inv.y * wc);
+}
+
+// |p - q| > 2e-6 |q| (also true when anything is not a number; false when both are zero)
+__device__ __forceinline__ bool differs_tight(float2 p, float2 q) {
+  const float dx = p.x - q.x, dy = p.y - q.y;
+  return !(fmaf(dx, dx, dy * dy) <= 4.0e-12f * fmaf(q.x, q.x, q.y * q.y));
+}
+
+// Staging of a' and k for elements base - RH .. base + CHUNK + RH - 1 (k: one more), in two halves so that the
+// global loads of the next chunk can be in flight while the current one is computed:
+//   load_ratio   global -> registers (17 rounds of 256 slots cover the RN + 1 = 4129 slots).  Outside the row a = 1,
+//                b = c = 0.  `full` (uniform): every index lies inside the row, no bounds logic.
+//   commit_ratio registers -> LDS: the operator's clamp / NaN rules, regularisation, k = b c.  Returns the NaN bits as
+//                stage_chunk does.
+constexpr int RNJ = E + 1;
+template <typename TIn>
+__device__ __forceinline__ void load_ratio(const TIn *__restrict__ a, const TIn *__restrict__ b,
+                                           const TIn *__restrict__ c, long base, long N, bool full, float (&av)[RNJ],
+                                           float (&bv)[RNJ], float (&cv)[RNJ]) {
+  const int t = threadIdx.x;
+  if (full) {
+#pragma unroll
+    for (int j = 0; j < RNJ; ++j) {
+      const int q = t + j * T;
+      const long i = base - RH + q;
+      av[j] = 1.0f;
+      bv[j] = 0.0f;
+      cv[j] = 0.0f;
+      if (j < E || q <= RN) {
+        av[j] = to_f32<TIn>(a[i]);
+        bv[j] = to_f32<TIn>(b[i - 1]);
+        cv[j] = to_f32<TIn>(c[i - 1]);
+      }
+    }
+  } else {
+    // branch-free: every load uses a clamped, always valid index (b and c must be readable at index 0 even when the
+    // row has no off-diagonal: the caller passes `a` for them then); out-of-row values are replaced afterwards
+    const long nk = max(N - 2, 0L);
+#pragma unroll
+    for (int j = 0; j < RNJ; ++j) {
+      const int q = min(t + j * T, RN);
+      const long i = base - RH + q;
+      av[j] = to_f32<TIn>(a[min(max(i, 0L), N - 1)]);
+      bv[j] = to_f32<TIn>(b[min(max(i - 1, 0L), nk)]);
+      cv[j] = to_f32<TIn>(c[min(max(i - 1, 0L), nk)]);
+    }
+#pragma unroll
+    for (int j = 0; j < RNJ; ++j) {
+      const long i = base - RH + (t + j * T);
+      const bool oka = i >= 0 && i < N;
+      const bool okk = i - 1 >= 0 && i - 1 <= N - 2;
+      av[j] = oka ? av[j] : 1.0f;
+      bv[j] = okk ? bv[j] : 0.0f;
+      cv[j] = okk ? cv[j] : 0.0f;
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned commit_ratio(const RowCfg &cfg, float (&av)[RNJ], float (&bv)[RNJ],
+                                                 float (&cv)[RNJ], SharedR &sh) {
+  unsigned seen = 0;
+  const int t = threadIdx.x;
+  if (!cfg.raw) {
+    float probe = 0.0f;
+#pragma unroll
+    for (int j = 0; j < RNJ; ++j) probe += av[j] + (bv[j] + cv[j]);
+    if (__builtin_expect(!__any(probe != probe), 1)) {
+#pragma unroll
+      for (int j = 0; j < RNJ; ++j) {
+        av[j] = __builtin_amdgcn_fmed3f(av[j], -100.0f, 100.0f);
+        bv[j] = __builtin_amdgcn_fmed3f(bv[j], -10.0f, 10.0f);
+        cv[j] = __builtin_amdgcn_fmed3f(cv[j], -10.0f, 10.0f);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < RNJ; ++j) {
+        float v = clamp_keep_nan(av[j], 100.0f);
+        if (v != v) { v = 0.0f; seen |= 1u; }
+        av[j] = v;
+        float p = clamp_keep_nan(bv[j], 10.0f), qv = clamp_keep_nan(cv[j], 10.0f);
+        if (p != p) { seen |= 2u; if (cfg.fix_bc) p = 1.0f; }
+        if (qv != qv) { seen |= 2u; if (cfg.fix_bc) qv = 1.0f; }
+        bv[j] = p;
+        cv[j] = qv;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < RNJ; ++j) {
+    const int q = t + j * T;
+    if (j < E || q <= RN) {
+      sh.u.in.k_s[rpad16(q)] = bv[j] * cv[j];
+      if (j < E || q < RN) sh.u.in.al_s[rpad16(q)] = reg_alpha(av[j], cfg);
+    }
+  }
+  return seen;
+}
+
+template <typename TIn, bool PHI_EXACT>
+__global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
+    const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
+    const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, float2 *__restrict__ G_,
+    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, unsigned flags) {
+  __shared__ SharedR sh;
+  const long row = blockIdx.x;
+  int *rowflag = reinterpret_cast<int *>(ws);
+  const TIn *a = a_ + row * lda;
+  const TIn *b = N >= 2 ? b_ + row * ldb : a;  // never used for data when N == 1, but must be readable
+  const TIn *c = N >= 2 ? c_ + row * ldc : a;
+  float2 *G = G_ + row * N;
+  float2 *F = F_ ? F_ + row * N : nullptr;
+  const int nch = (int)((N + CHUNK - 1) / CHUNK);
+  RowCfg cfg;
+  cfg.z = z_dev ? make_float2(z_dev[0], z_dev[1]) : make_float2(z_re, z_im);
+  cfg.N = N;
+  cfg.raw = (flags & BKCORE_FLAG_RAW) != 0;
+  cfg.fix_bc = false;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int seg = T - 1 - t;  // descending segments over ascending threads: the product runs right -> left
+  constexpr int KO = PHI_EXACT ? 1 : 0;
+  unsigned seen = 0;
+  bool bad = false;
+  int nscan = 0;
+  if (t == 0) sh.carry[0] = prod_one();
+
+  // raw inputs of the chunk about to be processed, loaded one chunk ahead
+  float av[RNJ], bv[RNJ], cv[RNJ];
+  auto prefetch = [&](int ch) __attribute__((always_inline)) {
+    // chunks 1 .. nch-3 lie at least a halo away from both ends of the row
+    load_ratio<TIn>(a, b, c, (long)ch * CHUNK, N, ch >= 1 && ch <= nch - 3, av, bv, cv);
+  };
+  auto one = [&](auto tail, int ch) __attribute__((always_inline)) {
+    constexpr bool TAIL = decltype(tail)::value;
+    const long base = (long)ch * CHUNK;
+
+    __syncthreads();  // previous chunk's output tile has been stored
+    seen |= commit_ratio(cfg, av, bv, cv, sh);
+
+    __syncthreads();
+    if (ch > 0) prefetch(ch - 1);  // in flight during this chunk's arithmetic
+
+    const int q0 = seg * E + RH;      // staged slot of the lane's first element (a multiple of 16)
+    const float2 *al_l = sh.u.in.al_s + rpad16(q0);
+    const float *k_l = sh.u.in.k_s + rpad16(q0);
+    const long i0 = base + (long)seg * E;
+    float2 ir[E];                     // 1 / r_e
+    float2 sv[E];                     // s_e; later the lane-local part of G_raw
+    // theta runs left -> right, phi right -> left; the two chains are independent and advance in the same loop
+    // iteration so that each wave always has two dependency chains in flight.  Warm-up: theta over the 16 elements
+    // to the left of the lane's own, phi over the 16 to the right.  Past the end of the row om_phi = 0
+    // (phi_{N+1} = 0: the recurrence starts with s_{N-1} = a'_{N-1}).
+    float2 wt = make_float2(0.f, 0.f), wp = make_float2(0.f, 0.f), r, inv;
+#pragma unroll
+    for (int j = 0; j < RH; ++j) {
+      wt = ratio_step(al_l[roff(j - RH)], k_l[roff(j - RH)], wt, r, inv);
+      const int d = E + RH - 1 - j;
+      wp = ratio_step(al_l[roff(d)], k_l[roff(d + KO)], wp, r, inv);
+      if (TAIL && i0 + d >= N) wp = make_float2(0.f, 0.f);
+    }
+    const float2 th_west = wt, ph_west = wp;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      wt = ratio_step(al_l[roff(j)], k_l[roff(j)], wt, r, inv);
+      ir[j] = inv;
+      const int e = E - 1 - j;
+      wp = ratio_step(al_l[roff(e)], k_l[roff(e + KO)], wp, r, inv);
+      if (TAIL && i0 + e >= N) wp = make_float2(0.f, 0.f);
+      sv[e] = r;
+    }
+    const float2 th_fin = wt, ph_fin = wp;
+
+    // lane-local products, descending: loc_e = (1/r_e) * prod_{e' > e} s_e' / r_e', exponents shared by groups of 4
+    Prod run = prod_one();
+    int le[E / 4];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      const int e = E - 1 - j;
+      const bool valid = !TAIL || i0 + e < N;
+      const float2 q1 = cmul(sv[e], ir[e]);  // s_e / r_e
+      sv[e] = cmul(ir[e], run.m);
+      if (valid) run.m = cmul(run.m, q1);
+      if ((e & 3) == 0) {  // end of a group of 4: record the exponent it was processed under, then renormalise
+        le[e >> 2] = run.e;
+        pnorm(run);
+      }
+    }
+
+    // workgroup exclusive product over ascending threads
+    Prod A = run;
+    A = pmul(A, prod_dpp<DPP_ROW_SHR1, 0xF>(A));
+    A = pmul(A, prod_dpp<DPP_ROW_SHR2, 0xF>(A));
+    A = pmul(A, prod_dpp<DPP_ROW_SHR4, 0xF>(A));
+    A = pmul(A, prod_dpp<DPP_ROW_SHR8, 0xF>(A));
+    A = pmul(A, prod_dpp<DPP_ROW_BCAST15, 0xA>(A));
+    A = pmul(A, prod_dpp<DPP_ROW_BCAST31, 0xC>(A));
+    const int buf = nscan & 1;
+    nscan++;
+    if (lane == 63) {
+      sh.tot[buf][wave] = A;
+      sh.wedge[buf][wave] = make_float4(th_west.x, th_west.y, ph_fin.x, ph_fin.y);
+    }
+    const Prod ex = prod_dpp<DPP_WAVE_SHR1, 0xF>(A);
+    const float4 nbv = make_float4(dpp_f<DPP_WAVE_SHR1, 0xF>(0.f, th_west.x), dpp_f<DPP_WAVE_SHR1, 0xF>(0.f, th_west.y),
+                                   dpp_f<DPP_WAVE_SHR1, 0xF>(0.f, ph_fin.x), dpp_f<DPP_WAVE_SHR1, 0xF>(0.f, ph_fin.y));
+    __syncthreads();
+    Prod v = sh.carry[buf];
+    Prod fin_in = v;
+#pragma unroll
+    for (int wv = 0; wv < WAVES; ++wv) {
+      if (wv == wave) fin_in = v;
+      v = pmul(v, sh.tot[buf][wv]);
+    }
+    if (t == 0) sh.carry[buf ^ 1] = v;
+    const Prod Fin = pmul(fin_in, ex);
+    // checks of the warm-up estimates against the neighbour that owns those elements (thread t - 1 owns the
+    // segment to the right; for thread 0 it is the first lane of the chunk processed before this one): the
+    // neighbour's theta warm-up ran over this lane's elements, this lane's phi warm-up over the neighbour's
+    {
+      float4 nb = nbv;  // thread t-1's (theta warm-up, phi end) inside the wave
+      if (lane == 0) nb = wave > 0 ? sh.wedge[buf][wave - 1] : sh.edge[buf ^ 1];
+      if (t > 0 || ch < nch - 1) {
+        bad |= differs_tight(make_float2(nb.x, nb.y), th_fin);
+        bad |= differs_tight(ph_west, make_float2(nb.z, nb.w));
+      }
+      if (t == T - 1) sh.edge[buf] = make_float4(th_west.x, th_west.y, ph_fin.x, ph_fin.y);
+    }
+
+    __syncthreads();  // staged inputs are dead: the tile may overwrite them
+
+    // epilogue (bk_core.py:190-208) into the output tile
+    float2 *slot = &sh.u.out_s[pad16(seg * E)];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float2 P = cmul(sv[e], Fin.m);
+      const int Ee = Fin.e + le[e >> 2];
+      const float n = fmaf(P.x, P.x, P.y * P.y);
+      const float L = LN2_HALF * fmaf(2.0f, (float)Ee, __builtin_amdgcn_logf(n));  // ln |G_raw|
+      const float sc = ldexpf(__builtin_amdgcn_exp2f(wall_exponent(L) * LOG2E), Ee);
+      float2 gv = make_float2(P.x * sc, P.y * sc);
+      const float m2 = fmaf(gv.x, gv.x, gv.y * gv.y);
+      if (__builtin_expect(!(m2 <= 2500.0f), 0)) {
+        const float u = 50.0f * __builtin_amdgcn_rsqf(n);
+        gv = (L > 3.9f && L <= 3.0e38f && u <= 3.0e38f) ? make_float2(P.x * u, P.y * u) : make_float2(0.f, 0.f);
+      }
+      slot[e] = gv;
+    }
+    __syncthreads();
+    float2 *__restrict__ Gc = G + base;
+    float2 *__restrict__ Fc = F ? F + base : nullptr;
+    const int n_here = TAIL ? (int)max(0L, min((long)CHUNK, N - base)) : CHUNK;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      const int idx = t + j * T;
+      if (!TAIL || idx < n_here) {
+        const float2 gv = fix_tiny(sh.u.out_s[pad16(idx)]);
+        Gc[idx] = gv;
+        if (Fc) Fc[idx] = gv;
+      }
+    }
+  };
+  // chunk kinds: the last two (anything at or past the end of the row within reach of a halo), then the others
+  prefetch(nch - 1);
+  int ch = nch - 1;
+  for (int n2 = 0; n2 < 2 && ch >= 0; ++n2, --ch) one(BoolC<true>{}, ch);
+  for (; ch >= 0; --ch) one(BoolC<false>{}, ch);
+  const int any_bad = __syncthreads_or(bad ? 1 : 0);
+  if (t == 0) {
+    rowflag[row] = any_bad;
+    if (any_bad) __hip_atomic_store(&state[2], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (seen) {
+    if (seen & 1u) __hip_atomic_store(&state[0], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen & 2u) __hip_atomic_store(&state[1], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ---- reference-mode backward (elementwise), bk_core.py:303-385 ------------------------------------------------
 __device__ __forceinline__ float nan_to_num_default(float v) {  // torch.nan_to_num defaults
   if (v != v) return 0.0f;
@@ -1383,8 +1753,23 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
       g_last_hip_error = (int)err;
       return BKCORE_ELAUNCH;
     }
+  } else if (state && !SAVE && !(flags & BKCORE_FLAG_SCAN_PATH)) {
+    // single-sweep ratio-form first launch, then the (normally empty) second launch for rows whose checks failed
+    hipLaunchKernelGGL((bk_ratio_forward_kernel<TIn, PHI_EXACT>), dim3((unsigned)B), dim3(T), 0, stream,
+                       (const TIn *)a, (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re,
+                       z_im, (long)B, (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id,
+                       flags);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess) {
+      BK_LAUNCH(false, 1);
+      err = hipGetLastError();
+    }
+    if (err != hipSuccess) {
+      g_last_hip_error = (int)err;
+      return BKCORE_ELAUNCH;
+    }
   } else if (state) {
-    // fast first launch, then the (normally empty) second launch for rows that need the two-scan path
+    // scan-based fast first launch, then the (normally empty) second launch for rows that need the two-scan path
     BK_LAUNCH(true, 0);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) {
