@@ -1,0 +1,28 @@
+"""Summarises rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (counter_collection.csv files given on the command
+line) per kernel and writes the corrected HBM traffic of the dominant forward kernel.
+FETCH_SIZE on gfx950 reports half the bytes of wide coalesced reads: doubled here.  Units: KiB in the CSV."""
+import collections, csv, json, re, sys
+
+out_path, B, N = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+agg = collections.defaultdict(list)
+for path in sys.argv[4:]:
+    for r in csv.DictReader(open(path)):
+        m = re.search(r"(bk_\w+)", r["Kernel_Name"])
+        if not m:
+            continue
+        name = m.group(1)
+        if name == "bk_forward_kernel":
+            name += "<second launch>" if "false" in r["Kernel_Name"].split("<")[1].split(",")[2] else "<scan first launch>"
+        agg[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
+summ = {}
+for (name, ctr), v in sorted(agg.items()):
+    summ[f"{name}|{ctr}"] = {"launches": len(v), "mean_KiB": sum(v) / len(v), "max_KiB": max(v)}
+fetch = summ.get("bk_ratio_forward_kernel|FETCH_SIZE", {}).get("mean_KiB", 0.0)
+write = summ.get("bk_ratio_forward_kernel|WRITE_SIZE", {}).get("mean_KiB", 0.0)
+total = (2.0 * fetch + write) * 1024.0
+res = {"counters": summ,
+       "note": "FETCH_SIZE on gfx950 reports half the bytes of wide coalesced reads; doubled. WRITE_SIZE is exact.",
+       "forward_traffic_bytes_per_launch_corrected": total,
+       "forward_traffic_bytes_per_elem_corrected": total / (B * N)}
+json.dump(res, open(out_path, "w"), indent=1)
+print(json.dumps({k: res[k] for k in ("forward_traffic_bytes_per_launch_corrected", "forward_traffic_bytes_per_elem_corrected")}))
