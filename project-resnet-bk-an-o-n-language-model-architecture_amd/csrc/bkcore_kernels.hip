@@ -1605,8 +1605,12 @@ __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
       const int idx = t + j * T;
       if (!TAIL || idx < n_here) {
         const float2 gv = fix_tiny(sh.u.out_s[pad16(idx)]);
-        Gc[idx] = gv;
-        if (Fc) Fc[idx] = gv;
+        __builtin_nontemporal_store(gv.x, &Gc[idx].x);
+        __builtin_nontemporal_store(gv.y, &Gc[idx].y);
+        if (Fc) {
+          __builtin_nontemporal_store(gv.x, &Fc[idx].x);
+          __builtin_nontemporal_store(gv.y, &Fc[idx].y);
+        }
       }
     }
   };
@@ -1682,7 +1686,8 @@ __global__ __launch_bounds__(256) void bk_backward_ref_kernel(const float2 *__re
     float2 o;
     o.x = bwd_ref_one(make_float2(Gv.x, Gv.y), make_float2(gv.x, gv.y), alpha);
     o.y = bwd_ref_one(make_float2(Gv.z, Gv.w), make_float2(gv.z, gv.w), alpha);
-    reinterpret_cast<float2 *>(out)[p] = o;
+    __builtin_nontemporal_store(o.x, &out[2 * p]);
+    __builtin_nontemporal_store(o.y, &out[2 * p + 1]);
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const long i = n - 1;
