@@ -1,0 +1,97 @@
+"""The small ResNet-BK LM around the operator: a training step on the GPU, and the data-parallel step (gradient
+all-reduce through DistributedDataParallel) on two CPU processes over gloo with the CPU oracle plugged in as the operator."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class _OracleOp(torch.autograd.Function):
+    """Oracle forward + reference-mode backward on the CPU (test stand-in for the HIP operator)."""
+    @staticmethod
+    def forward(ctx, a, b, c, z):
+        from oracle import bk_oracle_torch as O
+        feats, G = O.forward(a.float(), b.float(), c.float(), complex(z))
+        ctx.save_for_backward(G)
+        return feats, G
+
+    @staticmethod
+    def backward(ctx, gf, gG):
+        from oracle import bk_oracle_torch as O
+        (G,) = ctx.saved_tensors
+        return O.backward_reference(G, gf, gG, 0.5), None, None, None
+
+
+def _tiny_model():
+    from bkcore.lm import SmallResNetBKLM
+    torch.manual_seed(3)
+    m = SmallResNetBKLM(vocab_size=101, d_model=16, n_layers=2, n_seq=24)
+    with torch.no_grad():
+        for blk in m.blocks:
+            blk.bk_layer.v_proj.weight.normal_(0.0, 0.3)
+    return m
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bkcore.lm import training_step
+        m = _tiny_model()
+        m.set_bk_core(_OracleOp.apply)
+        ddp = torch.nn.parallel.DistributedDataParallel(m)
+        opt = torch.optim.SGD(ddp.parameters(), lr=0.0)          # lr 0: keep the weights, inspect the gradients
+        g = torch.Generator().manual_seed(10 + rank)
+        tok = torch.randint(0, 101, (2, 24), generator=g)
+        tgt = torch.randint(0, 101, (2, 24), generator=g)
+        training_step(ddp, opt, tok, tgt, grad_clip=1e9)
+        if rank == 0:
+            out["ddp"] = m.blocks[0].bk_layer.v_proj.weight.grad.clone().numpy()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_averages_gradients():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+        got = out["ddp"]
+    # the same two batches through one process: the mean of the per-batch gradients
+    from bkcore.lm import training_step
+    grads = []
+    for rank in range(2):
+        m = _tiny_model()
+        m.set_bk_core(_OracleOp.apply)
+        opt = torch.optim.SGD(m.parameters(), lr=0.0)
+        g = torch.Generator().manual_seed(10 + rank)
+        tok = torch.randint(0, 101, (2, 24), generator=g)
+        tgt = torch.randint(0, 101, (2, 24), generator=g)
+        training_step(m, opt, tok, tgt, grad_clip=1e9)
+        grads.append(m.blocks[0].bk_layer.v_proj.weight.grad.numpy())
+    ref = 0.5 * (grads[0] + grads[1])
+    assert np.abs(ref).max() > 0
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_training_steps_on_gpu_reduce_the_loss():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bkcore.lm import SmallResNetBKLM, training_step
+    torch.manual_seed(0)
+    model = SmallResNetBKLM(vocab_size=1000, d_model=64, n_layers=2, n_seq=128).cuda()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    tok = torch.randint(0, 1000, (4, 128), device="cuda", generator=g)
+    tgt = torch.randint(0, 1000, (4, 128), device="cuda", generator=g)
+    losses = [float(training_step(model, opt, tok, tgt)) for _ in range(8)]
+    assert all(np.isfinite(losses))
+    assert abs(losses[0] - np.log(1000)) < 0.5                   # random init: about ln(vocab)
+    assert losses[-1] < losses[0]
+    gv = model.blocks[0].bk_layer.v_proj.weight.grad
+    assert gv is not None and torch.isfinite(gv).all() and gv.abs().max() > 0

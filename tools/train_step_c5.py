@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""End-to-end training step of the small ResNet-BK LM with the HIP BK-Core (BASELINE.json configs[4]).
+
+    python tools/train_step_c5.py [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_step_c5.py
+
+One process per GPU; with more than one, DistributedDataParallel over RCCL averages the gradients (the only
+communication: the operator itself shards by batch row).  Dummy token batches, random-init weights.  Rank 0 prints one
+JSON line with tokens/s over all ranks."""
+import argparse, json, os, sys, time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "project-resnet-bk-an-o-n-language-model-architecture_amd"))
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8)
+    args = ap.parse_args()
+    rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    from bkcore.lm import SmallResNetBKLM, training_step
+    torch.manual_seed(0)
+    model = SmallResNetBKLM().to(device)
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index])
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01)
+    g = torch.Generator(device=device).manual_seed(100 + rank)
+    n_seq = 256
+    tokens = torch.randint(0, 50257, (args.batch, n_seq), device=device, generator=g)
+    targets = torch.randint(0, 50257, (args.batch, n_seq), device=device, generator=g)
+    for _ in range(args.warmup):
+        loss = training_step(model, opt, tokens, targets)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = training_step(model, opt, tokens, targets)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        print(json.dumps({"metric": "resnet_bk_small_lm_train_tokens_per_sec", "value": world * args.batch * n_seq * args.steps / dt,
+                          "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
+                          "final_loss": float(loss), "config": {"workload": "phase7_small dims: d_model 256, 4 layers, n_seq 256, "
+                          f"batch {args.batch}/GPU, vocab 50257, AdamW 1e-4, clip 1.0; dummy tokens", "parallelism": f"dp{world}"}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
