@@ -1368,40 +1368,37 @@ __device__ __forceinline__ void load_ratio(const TIn *__restrict__ a, const TIn 
                                            const TIn *__restrict__ c, long base, long N, bool full, float (&av)[RNJ],
                                            float (&bv)[RNJ], float (&cv)[RNJ]) {
   const int t = threadIdx.x;
+  // 32-bit offsets from uniform bases (scalar base + vector offset addressing); slot q holds element base - RH + q
+  const TIn *__restrict__ a0 = a + (base - RH);
+  const TIn *__restrict__ b0 = b + (base - RH - 1);
+  const TIn *__restrict__ c0 = c + (base - RH - 1);
   if (full) {
 #pragma unroll
     for (int j = 0; j < RNJ; ++j) {
-      const int q = t + j * T;
-      const long i = base - RH + q;
-      av[j] = 1.0f;
-      bv[j] = 0.0f;
-      cv[j] = 0.0f;
-      if (j < E || q <= RN) {
-        av[j] = to_f32<TIn>(a[i]);
-        bv[j] = to_f32<TIn>(b[i - 1]);
-        cv[j] = to_f32<TIn>(c[i - 1]);
-      }
+      const int q = min(t + j * T, RN);
+      av[j] = to_f32<TIn>(a0[q]);
+      bv[j] = to_f32<TIn>(b0[q]);
+      cv[j] = to_f32<TIn>(c0[q]);
     }
   } else {
     // branch-free: every load uses a clamped, always valid index (b and c must be readable at index 0 even when the
     // row has no off-diagonal: the caller passes `a` for them then); out-of-row values are replaced afterwards
-    const long nk = max(N - 2, 0L);
+    const int lo_a = (int)max(0L, RH - base);                  // first slot whose element index is >= 0
+    const int hi_a = (int)min((long)RN, N - 1 - (base - RH));  // last slot whose element index is <= N-1 (may be < lo)
+    const int lo_k = (int)max(0L, RH + 1 - base);              // k index = element index - 1 >= 0
+    const int hi_k = (int)min((long)RN, N - 2 - (base - RH - 1));
+    const int ca = max(hi_a, lo_a), ck = max(hi_k, lo_k);
 #pragma unroll
     for (int j = 0; j < RNJ; ++j) {
       const int q = min(t + j * T, RN);
-      const long i = base - RH + q;
-      av[j] = to_f32<TIn>(a[min(max(i, 0L), N - 1)]);
-      bv[j] = to_f32<TIn>(b[min(max(i - 1, 0L), nk)]);
-      cv[j] = to_f32<TIn>(c[min(max(i - 1, 0L), nk)]);
-    }
-#pragma unroll
-    for (int j = 0; j < RNJ; ++j) {
-      const long i = base - RH + (t + j * T);
-      const bool oka = i >= 0 && i < N;
-      const bool okk = i - 1 >= 0 && i - 1 <= N - 2;
-      av[j] = oka ? av[j] : 1.0f;
-      bv[j] = okk ? bv[j] : 0.0f;
-      cv[j] = okk ? cv[j] : 0.0f;
+      const int qa = min(max(q, lo_a), ca);
+      const int qk = min(max(q, lo_k), ck);
+      const float va = to_f32<TIn>(a0[qa]);
+      const float vb = to_f32<TIn>(b0[N >= 2 ? qk : qa + 1]);
+      const float vc = to_f32<TIn>(c0[N >= 2 ? qk : qa + 1]);
+      av[j] = (q >= lo_a && q <= hi_a) ? va : 1.0f;
+      bv[j] = (q >= lo_k && q <= hi_k) ? vb : 0.0f;
+      cv[j] = (q >= lo_k && q <= hi_k) ? vc : 0.0f;
     }
   }
 }
