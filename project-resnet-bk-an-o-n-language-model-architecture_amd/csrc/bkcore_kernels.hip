@@ -1443,20 +1443,33 @@ __device__ __forceinline__ unsigned commit_ratio(const RowCfg &cfg, float (&av)[
   return seen;
 }
 
-template <typename TIn, bool PHI_EXACT>
+// MODE 0: one workgroup per row.  Few long rows (split_plan) are cut into S segments of seg_ch chunks, one workgroup
+// each, in two launches around bk_ratio_combine_kernel: the chunks of a row are independent except for the running
+// product, so MODE 1 computes only each segment's product (and its checks; no outputs), the combine kernel turns
+// those into the product entering each segment and checks the estimates across segment boundaries, and MODE 2 is
+// the full computation of each segment started from that product.
+// Per-segment record (floats): [0,1] product mantissa, [2] exponent, [3] a check failed, [4..7] right edge
+// (theta end value, phi warm-up of the last lane), [8..11] left edge (theta warm-up, phi end value of the first lane),
+// [12,13] mantissa and [14] exponent of the product entering the segment.
+template <typename TIn, bool PHI_EXACT, int MODE>
 __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
     const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
     const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, float2 *__restrict__ G_,
-    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, unsigned flags) {
+    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, unsigned flags, int S, int seg_ch) {
   __shared__ SharedR sh;
-  const long row = blockIdx.x;
+  const long row = MODE == 0 ? (long)blockIdx.x : (long)(blockIdx.x / S);
+  const int sg = MODE == 0 ? 0 : (int)(blockIdx.x % S);
   int *rowflag = reinterpret_cast<int *>(ws);
+  if (MODE == 2 && rowflag[row] != 0) return;  // the whole row is recomputed by the scan kernel
   const TIn *a = a_ + row * lda;
   const TIn *b = N >= 2 ? b_ + row * ldb : a;  // never used for data when N == 1, but must be readable
   const TIn *c = N >= 2 ? c_ + row * ldc : a;
   float2 *G = G_ + row * N;
   float2 *F = F_ ? F_ + row * N : nullptr;
   const int nch = (int)((N + CHUNK - 1) / CHUNK);
+  const int ch0 = MODE == 0 ? 0 : sg * seg_ch;
+  const int ch1 = MODE == 0 ? nch : min(nch, ch0 + seg_ch);
+  float *info = reinterpret_cast<float *>(ws + rowflag_bytes(B) + lane_state_bytes(B, N)) + (row * S + sg) * SEG_INFO;
   RowCfg cfg;
   cfg.z = z_dev ? make_float2(z_dev[0], z_dev[1]) : make_float2(z_re, z_im);
   cfg.N = N;
@@ -1470,7 +1483,14 @@ __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
   unsigned seen = 0;
   bool bad = false;
   int nscan = 0;
-  if (t == 0) sh.carry[0] = prod_one();
+  if (t == 0) {
+    Prod p0 = prod_one();
+    if (MODE == 2) {
+      p0.m = make_float2(info[12], info[13]);
+      p0.e = __float_as_int(info[14]);
+    }
+    sh.carry[0] = p0;
+  }
 
   // raw inputs of the chunk about to be processed, loaded one chunk ahead
   float av[RNJ], bv[RNJ], cv[RNJ];
@@ -1486,7 +1506,7 @@ __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
     seen |= commit_ratio(cfg, av, bv, cv, sh);
 
     __syncthreads();
-    if (ch > 0) prefetch(ch - 1);  // in flight during this chunk's arithmetic
+    if (ch > ch0) prefetch(ch - 1);  // in flight during this chunk's arithmetic
 
     const int q0 = seg * E + RH;      // staged slot of the lane's first element (a multiple of 16)
     const float2 *al_l = sh.u.in.al_s + rpad16(q0);
@@ -1567,12 +1587,21 @@ __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
     {
       float4 nb = nbv;  // thread t-1's (theta warm-up, phi end) inside the wave
       if (lane == 0) nb = wave > 0 ? sh.wedge[buf][wave - 1] : sh.edge[buf ^ 1];
-      if (t > 0 || ch < nch - 1) {
+      if (t > 0 || ch < ch1 - 1) {
         bad |= differs_tight(make_float2(nb.x, nb.y), th_fin);
         bad |= differs_tight(ph_west, make_float2(nb.z, nb.w));
       }
       if (t == T - 1) sh.edge[buf] = make_float4(th_west.x, th_west.y, ph_fin.x, ph_fin.y);
+      if (MODE == 1) {  // the two ends of the segment are checked against its neighbours by the combine kernel
+        if (t == 0 && ch == ch1 - 1) {
+          info[4] = th_fin.x; info[5] = th_fin.y; info[6] = ph_west.x; info[7] = ph_west.y;
+        }
+        if (t == T - 1 && ch == ch0) {
+          info[8] = th_west.x; info[9] = th_west.y; info[10] = ph_fin.x; info[11] = ph_fin.y;
+        }
+      }
     }
+    if (MODE == 1) return;  // only the product was wanted
 
     __syncthreads();  // staged inputs are dead: the tile may overwrite them
 
@@ -1612,18 +1641,87 @@ __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
     }
   };
   // chunk kinds: the last two (anything at or past the end of the row within reach of a halo), then the others
-  prefetch(nch - 1);
-  int ch = nch - 1;
-  for (int n2 = 0; n2 < 2 && ch >= 0; ++n2, --ch) one(BoolC<true>{}, ch);
-  for (; ch >= 0; --ch) one(BoolC<false>{}, ch);
+  prefetch(ch1 - 1);
+  int ch = ch1 - 1;
+  for (; ch >= ch0 && ch >= nch - 2; --ch) one(BoolC<true>{}, ch);
+  for (; ch >= ch0; --ch) one(BoolC<false>{}, ch);
   const int any_bad = __syncthreads_or(bad ? 1 : 0);
   if (t == 0) {
-    rowflag[row] = any_bad;
-    if (any_bad) __hip_atomic_store(&state[2], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (MODE == 0) {
+      rowflag[row] = any_bad;
+      if (any_bad) __hip_atomic_store(&state[2], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (MODE == 1) {
+      const Prod tot = sh.carry[nscan & 1];  // started from one: the segment's own product
+      info[0] = tot.m.x;
+      info[1] = tot.m.y;
+      info[2] = __int_as_float(tot.e);
+      info[3] = any_bad ? 1.0f : 0.0f;
+    } else if (any_bad) {
+      atomicOr(&rowflag[row], 1);
+      __hip_atomic_store(&state[2], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   if (seen) {
     if (seen & 1u) __hip_atomic_store(&state[0], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (seen & 2u) __hip_atomic_store(&state[1], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// One wave per row, one lane per segment (64 at a time, right to left): the product entering each segment, the
+// checks across segment boundaries, the row's verdict.
+__global__ __launch_bounds__(64) void bk_ratio_combine_kernel(long B, long N, char *__restrict__ ws, int *state,
+                                                              int call_id, int S) {
+  const long row = blockIdx.x;
+  const int lane = threadIdx.x;
+  int *rowflag = reinterpret_cast<int *>(ws);
+  float *info = reinterpret_cast<float *>(ws + rowflag_bytes(B) + lane_state_bytes(B, N)) + row * S * SEG_INFO;
+  bool bad = false;
+  Prod carry = prod_one();
+  for (int g0 = 0; g0 < S; g0 += 64) {
+    const int idx = g0 + lane;
+    const int sg = S - 1 - idx;  // ascending lanes = segments right to left
+    Prod q = prod_one();
+    if (idx < S) {
+      const float *me = info + sg * SEG_INFO;
+      q.m = make_float2(me[0], me[1]);
+      q.e = __float_as_int(me[2]);
+      bad |= me[3] != 0.0f;
+      if (sg < S - 1) {
+        const float *rt = me + SEG_INFO;  // the segment to the right
+        bad |= differs_tight(make_float2(rt[8], rt[9]), make_float2(me[4], me[5]));
+        bad |= differs_tight(make_float2(me[6], me[7]), make_float2(rt[10], rt[11]));
+      }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      Prod o;
+      o.m.x = __shfl_up(q.m.x, d);
+      o.m.y = __shfl_up(q.m.y, d);
+      o.e = __shfl_up(q.e, d);
+      if (lane >= d) q = pmul(q, o);
+    }
+    Prod ex;
+    ex.m.x = __shfl_up(q.m.x, 1);
+    ex.m.y = __shfl_up(q.m.y, 1);
+    ex.e = __shfl_up(q.e, 1);
+    if (lane == 0) ex = prod_one();
+    ex = pmul(carry, ex);
+    if (idx < S) {
+      float *me = info + sg * SEG_INFO;
+      me[12] = ex.m.x;
+      me[13] = ex.m.y;
+      me[14] = __int_as_float(ex.e);
+    }
+    Prod last;
+    last.m.x = __shfl(q.m.x, 63);
+    last.m.y = __shfl(q.m.y, 63);
+    last.e = __shfl(q.e, 63);
+    carry = pmul(carry, last);
+  }
+  const int any_bad = __syncthreads_or(bad ? 1 : 0);
+  if (lane == 0) {
+    rowflag[row] = any_bad ? 1 : 0;
+    if (any_bad) __hip_atomic_store(&state[2], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1735,8 +1833,30 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
                      SECOND, flags, (float2 *)save_r, (float2 *)save_s)
   int S = 1, seg_ch = 0;
   if (state && !SAVE) split_plan(B, N, S, seg_ch);
-  if (S > 1) {
-    // few long rows: several workgroups per row, then the (normally empty) launch for rows whose checks failed
+  if (S > 1 && !(flags & BKCORE_FLAG_SCAN_PATH)) {
+    // few long rows, ratio form: segment products, combine, segment outputs, then the (normally empty) launch of
+    // the scan kernel for rows whose checks failed
+    const unsigned grid = (unsigned)(B * S);
+#define BK_RATIO_SEG(MODE)                                                                                           \
+  hipLaunchKernelGGL((bk_ratio_forward_kernel<TIn, PHI_EXACT, MODE>), dim3(grid), dim3(T), 0, stream, (const TIn *)a, \
+                     (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re, z_im, (long)B,     \
+                     (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id, flags, S, seg_ch)
+    BK_RATIO_SEG(1);
+    hipLaunchKernelGGL(bk_ratio_combine_kernel, dim3((unsigned)B), dim3(64), 0, stream, (long)B, (long)N, (char *)ws,
+                       (int *)state, call_id, S);
+    BK_RATIO_SEG(2);
+#undef BK_RATIO_SEG
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess) {
+      BK_LAUNCH(false, 1);
+      err = hipGetLastError();
+    }
+    if (err != hipSuccess) {
+      g_last_hip_error = (int)err;
+      return BKCORE_ELAUNCH;
+    }
+  } else if (S > 1) {
+    // few long rows, scan form: several workgroups per row, then the launch for rows whose checks failed
     const unsigned grid = (unsigned)(B * S);
     hipLaunchKernelGGL((bk_split_aggregate_kernel<TIn, PHI_EXACT>), dim3(grid), dim3(T), 0, stream, (const TIn *)a,
                        (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re, z_im, (long)B,
@@ -1757,10 +1877,10 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
     }
   } else if (state && !SAVE && !(flags & BKCORE_FLAG_SCAN_PATH)) {
     // single-sweep ratio-form first launch, then the (normally empty) second launch for rows whose checks failed
-    hipLaunchKernelGGL((bk_ratio_forward_kernel<TIn, PHI_EXACT>), dim3((unsigned)B), dim3(T), 0, stream,
+    hipLaunchKernelGGL((bk_ratio_forward_kernel<TIn, PHI_EXACT, 0>), dim3((unsigned)B), dim3(T), 0, stream,
                        (const TIn *)a, (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re,
                        z_im, (long)B, (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id,
-                       flags);
+                       flags, 1, 0);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) {
       BK_LAUNCH(false, 1);

@@ -225,14 +225,17 @@ def test_long_sequence(bk, coracle):
                                             (3, 40000, torch.float32, "exact"),
                                             (5, 8 * 4096, torch.bfloat16, "reference"),
                                             (1, 300001, torch.float64, "reference")])
-def test_few_long_rows_use_several_workgroups_per_row(bk, coracle, B, N, dtype, conv):
-    """B <= 128 and N >= 8 chunks: rows are cut into segments (one workgroup each).  Parity against the oracle and no
-    row falling back to the one-workgroup path on well-conditioned input."""
+@pytest.mark.parametrize("scan_path", [False, True])
+def test_few_long_rows_use_several_workgroups_per_row(bk, coracle, B, N, dtype, conv, scan_path):
+    """B <= 128 and N >= 8 chunks: rows are cut into segments (one workgroup each), in ratio form by default and in
+    scan form with BKCORE_FLAG_SCAN_PATH.  Parity against the oracle and no row falling back to the one-workgroup
+    kernel on well-conditioned input."""
     from bkcore import bk_core
     a, b, c = _lap(B, N, 17 + B, varying=True)
     a, b, c = a.to(dtype), b.to(dtype), c.to(dtype)
     z = 0.3 + 0.9j
     bk_core._DEBUG["keep_ws"] = True
+    bk_core._DEBUG["scan_path"] = scan_path
     bk.BKCoreFunction.PHI_K_INDEX = conv
     try:
         feats, G = bk.BKCoreFunction.apply(a.cuda(), b.cuda(), c.cuda(), z)
@@ -241,6 +244,7 @@ def test_few_long_rows_use_several_workgroups_per_row(bk, coracle, B, N, dtype, 
     finally:
         bk.BKCoreFunction.PHI_K_INDEX = "reference"
         bk_core._DEBUG["keep_ws"] = False
+        bk_core._DEBUG["scan_path"] = False
         bk_core._DEBUG["last_ws"] = None
     Gref = coracle.get_diag(a.double().numpy(), b.double().numpy(), c.double().numpy(), z, phi_exact=(conv == "exact"))
     assert max_rel_err(G.cpu().numpy(), Gref) <= TOL
