@@ -187,6 +187,13 @@ def main():
             "hbm_frac_fwd_bwd": (FWD_BYTES + BWD_BYTES) * elems / (t_fwd + t_bwd) / HBM_PEAK,
         }
         if world == 1:
+            # what a plain device-to-device copy of the same volume reaches on this box (read + write bytes / time)
+            with torch.no_grad():
+                src = torch.empty(B, N, 2, device=device)
+                dst = torch.empty_like(src)
+                t_copy = timed(lambda: dst.copy_(src), reps)
+                out["roofline"]["copy_ceiling_GBps"] = 2 * src.numel() * 4 / t_copy / 1e9
+                del src, dst
             # secondary measurements (not part of `value`): analytic-mode backward at the same size, and the
             # long-context configuration BASELINE.json configs[2] (B=16, N=2^20: several workgroups per row)
             with torch.no_grad():
