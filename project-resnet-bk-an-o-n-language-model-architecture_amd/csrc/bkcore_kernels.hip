@@ -1328,6 +1328,30 @@ __device__ __forceinline__ int rpad16(int q) { return q + (q >> 4); }
 // staged slot q0 + d of a lane whose first slot q0 is a multiple of 16: base + roff(d), d a compile-time constant
 __device__ __forceinline__ constexpr int roff(int d) { return d + (d >= 0 ? d / 16 : -((15 - d) / 16)); }
 
+// A lane's 16 consecutive complex values as eight 16-byte stores (the struct is only 4-byte aligned: rows start
+// anywhere); `count` < 16 only at the ragged end of a row.
+struct __attribute__((aligned(4))) F4u {
+  float v[4];
+};
+__device__ __forceinline__ void store_lane_block(float2 *__restrict__ dst, const float2 (&v)[E], int count) {
+  float *p = reinterpret_cast<float *>(dst);
+  if (count >= E) {
+#pragma unroll
+    for (int q = 0; q < E / 2; ++q) {
+      F4u t;
+      t.v[0] = v[2 * q].x;
+      t.v[1] = v[2 * q].y;
+      t.v[2] = v[2 * q + 1].x;
+      t.v[3] = v[2 * q + 1].y;
+      *reinterpret_cast<F4u *>(p + 4 * q) = t;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (e < count) dst[e] = v[e];
+  }
+}
+
 // One step of either ratio map: r = al - k * om_prev; returns om(r) and hands back r and 1/r.  The reciprocal of
 // |r|^2 is refined by one Newton step and the clamp factor exp(g) is an exp2 of a tiny argument: the hardware log
 // and exp2 round with a bias of a fraction of an ulp, which is harmless inside the contracting recurrence and in g,
@@ -1451,11 +1475,14 @@ __device__ __forceinline__ unsigned commit_ratio(const RowCfg &cfg, float (&av)[
 // Per-segment record (floats): [0,1] product mantissa, [2] exponent, [3] a check failed, [4..7] right edge
 // (theta end value, phi warm-up of the last lane), [8..11] left edge (theta warm-up, phi end value of the first lane),
 // [12,13] mantissa and [14] exponent of the product entering the segment.
-template <typename TIn, bool PHI_EXACT, int MODE>
+// SAVE (MODE 0 only, for the analytic backward): also stores r_j and s_j, and writes G_raw (before the final
+// log-magnitude clamp and the clip; 0 outside 1e-18 <= |G_raw| <= 1e18) instead of G.
+template <typename TIn, bool PHI_EXACT, int MODE, bool SAVE = false>
 __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
     const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
     const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, float2 *__restrict__ G_,
-    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, unsigned flags, int S, int seg_ch) {
+    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, unsigned flags, int S, int seg_ch,
+    float2 *__restrict__ save_r_ = nullptr, float2 *__restrict__ save_s_ = nullptr) {
   __shared__ SharedR sh;
   const long row = MODE == 0 ? (long)blockIdx.x : (long)(blockIdx.x / S);
   const int sg = MODE == 0 ? 0 : (int)(blockIdx.x % S);
@@ -1537,6 +1564,17 @@ __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
       sv[e] = r;
     }
     const float2 th_fin = wt, ph_fin = wp;
+    if (SAVE) {
+      const int cnt = TAIL ? (int)max(0L, min((long)E, N - i0)) : E;
+      store_lane_block(save_s_ + row * N + i0, sv, cnt);
+      float2 rv[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {  // r = 1 / (1/r)
+        const float y = 1.0f / fmaf(ir[e].x, ir[e].x, ir[e].y * ir[e].y);
+        rv[e] = make_float2(ir[e].x * y, -ir[e].y * y);
+      }
+      store_lane_block(save_r_ + row * N + i0, rv, cnt);
+    }
 
     // lane-local products, descending: loc_e = (1/r_e) * prod_{e' > e} s_e' / r_e', exponents shared by groups of 4
     Prod run = prod_one();
@@ -1613,12 +1651,17 @@ __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
       const int Ee = Fin.e + le[e >> 2];
       const float n = fmaf(P.x, P.x, P.y * P.y);
       const float L = LN2_HALF * fmaf(2.0f, (float)Ee, __builtin_amdgcn_logf(n));  // ln |G_raw|
-      const float sc = ldexpf(__builtin_amdgcn_exp2f(wall_exponent(L) * LOG2E), Ee);
-      float2 gv = make_float2(P.x * sc, P.y * sc);
-      const float m2 = fmaf(gv.x, gv.x, gv.y * gv.y);
-      if (__builtin_expect(!(m2 <= 2500.0f), 0)) {
-        const float u = 50.0f * __builtin_amdgcn_rsqf(n);
-        gv = (L > 3.9f && L <= 3.0e38f && u <= 3.0e38f) ? make_float2(P.x * u, P.y * u) : make_float2(0.f, 0.f);
+      float2 gv;
+      if (SAVE) {
+        gv = (fabsf(L) <= 41.4f) ? make_float2(ldexpf(P.x, Ee), ldexpf(P.y, Ee)) : make_float2(0.f, 0.f);
+      } else {
+        const float sc = ldexpf(__builtin_amdgcn_exp2f(wall_exponent(L) * LOG2E), Ee);
+        gv = make_float2(P.x * sc, P.y * sc);
+        const float m2 = fmaf(gv.x, gv.x, gv.y * gv.y);
+        if (__builtin_expect(!(m2 <= 2500.0f), 0)) {
+          const float u = 50.0f * __builtin_amdgcn_rsqf(n);
+          gv = (L > 3.9f && L <= 3.0e38f && u <= 3.0e38f) ? make_float2(P.x * u, P.y * u) : make_float2(0.f, 0.f);
+        }
       }
       slot[e] = gv;
     }
@@ -1630,7 +1673,7 @@ __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
     for (int j = 0; j < E; ++j) {
       const int idx = t + j * T;
       if (!TAIL || idx < n_here) {
-        const float2 gv = fix_tiny(sh.u.out_s[pad16(idx)]);
+        const float2 gv = SAVE ? sh.u.out_s[pad16(idx)] : fix_tiny(sh.u.out_s[pad16(idx)]);
         __builtin_nontemporal_store(gv.x, &Gc[idx].x);
         __builtin_nontemporal_store(gv.y, &Gc[idx].y);
         if (Fc) {
@@ -1875,12 +1918,12 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
       g_last_hip_error = (int)err;
       return BKCORE_ELAUNCH;
     }
-  } else if (state && !SAVE && !(flags & BKCORE_FLAG_SCAN_PATH)) {
+  } else if (state && !(flags & BKCORE_FLAG_SCAN_PATH)) {
     // single-sweep ratio-form first launch, then the (normally empty) second launch for rows whose checks failed
-    hipLaunchKernelGGL((bk_ratio_forward_kernel<TIn, PHI_EXACT, 0>), dim3((unsigned)B), dim3(T), 0, stream,
+    hipLaunchKernelGGL((bk_ratio_forward_kernel<TIn, PHI_EXACT, 0, SAVE>), dim3((unsigned)B), dim3(T), 0, stream,
                        (const TIn *)a, (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re,
                        z_im, (long)B, (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id,
-                       flags, 1, 0);
+                       flags, 1, 0, (float2 *)save_r, (float2 *)save_s);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) {
       BK_LAUNCH(false, 1);
