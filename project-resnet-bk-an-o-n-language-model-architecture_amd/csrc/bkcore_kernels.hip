@@ -1362,15 +1362,15 @@ __device__ __forceinline__ float2 ratio_step(float2 al, float k, float2 om, floa
   float y = __builtin_amdgcn_rcpf(n);
   y = fmaf(y, fmaf(-n, y, 1.0f), y);
   inv = make_float2(r.x * y, -r.y * y);
-  // clamp factor exp(g(d)), d = -ln|r| = -(ln 2 / 2) log2 |r|^2, |d| limited to 22.  g = -88 (u^3/3 - 2u^5/15 +
-  // 17u^7/315), u = d/88 (|u| <= 1/4: relative error of g below 2e-5); exp(g) by its series to g^3 (|g| <= 0.02 for
-  // any |r| between 1e-3 and 1e9; the clamp is a 1e-5 effect, so 1e-3 of it is far below float32 resolution).
+  // clamp factor exp(g(d)), d = -ln|r| = -(ln 2 / 2) log2 |r|^2, |d| limited to 22.  g = -88 (u^3/3 - 2u^5/15),
+  // u = d/88 (|u| <= 1/4: relative error of g below 7e-4, and below 1e-6 for |r| between 1e-2 and 1e2); exp(g) by
+  // its series to g^2 (|g| <= 0.02 for any |r| between 1e-3 and 1e9: 1.4e-6 there, 1e-14 at |r| ~ 2).  The clamp is
+  // a 1e-5 effect on k, so 1e-3 of it is far below float32 resolution.
   const float u = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(n) * (-LN2_HALF / 88.0f), -0.25f, 0.25f);
   const float s2 = u * u;
-  float p = fmaf(s2, -88.0f * 17.0f / 315.0f, 88.0f * 2.0f / 15.0f);
-  p = fmaf(s2, p, -88.0f / 3.0f);
+  const float p = fmaf(s2, 88.0f * 2.0f / 15.0f, -88.0f / 3.0f);
   const float g = (u * s2) * p;
-  const float wc = fmaf(g, fmaf(g, fmaf(g, 1.0f / 6.0f, 0.5f), 1.0f), 1.0f);
+  const float wc = fmaf(g, fmaf(g, 0.5f, 1.0f), 1.0f);
   return make_float2(inv.x * wc, inv.y * wc);
 }
 
@@ -1565,15 +1565,31 @@ __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
     }
     const float2 th_fin = wt, ph_fin = wp;
     if (SAVE) {
-      const int cnt = TAIL ? (int)max(0L, min((long)E, N - i0)) : E;
-      store_lane_block(save_s_ + row * N + i0, sv, cnt);
-      float2 rv[E];
+      // r and s leave through the output tile (it overlays the staging area: wait until every wave's chains are done)
+      const int n_sv = TAIL ? (int)max(0L, min((long)CHUNK, N - base)) : CHUNK;
+      float2 *slot_sv = &sh.u.out_s[pad16(seg * E)];
+#pragma unroll 1
+      for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+        if (pass == 0) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) {  // r = 1 / (1/r)
-        const float y = 1.0f / fmaf(ir[e].x, ir[e].x, ir[e].y * ir[e].y);
-        rv[e] = make_float2(ir[e].x * y, -ir[e].y * y);
+          for (int e = 0; e < E; ++e) {  // r = 1 / (1/r)
+            const float y = 1.0f / fmaf(ir[e].x, ir[e].x, ir[e].y * ir[e].y);
+            slot_sv[e] = make_float2(ir[e].x * y, -ir[e].y * y);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < E; ++e) slot_sv[e] = sv[e];
+        }
+        __syncthreads();
+        float2 *__restrict__ dst = (pass == 0 ? save_r_ : save_s_) + row * N + base;
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+          const int idx = t + j * T;
+          if (!TAIL || idx < n_sv) dst[idx] = sh.u.out_s[pad16(idx)];
+        }
       }
-      store_lane_block(save_r_ + row * N + i0, rv, cnt);
+      __syncthreads();
     }
 
     // lane-local products, descending: loc_e = (1/r_e) * prod_{e' > e} s_e' / r_e', exponents shared by groups of 4
