@@ -1275,8 +1275,8 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_split_output_kernel(
 #endif
 constexpr int RH = 16;                          // warm-up length = halo staged on both sides of a chunk
 constexpr int RN = CHUNK + 2 * RH;              // staged elements per chunk
-constexpr int RAL_PAD = RN + RN / 16 + 8;       // float2 entries, index q + q/16
-constexpr int RK_PAD = RN + 1 + (RN + 1) / 16 + 8;
+constexpr int RAL_PAD = RN + RN / E + 8;        // float2 entries, index q + q/E
+constexpr int RK_PAD = RN + 1 + (RN + 1) / E + 8;
 
 struct Prod {  // complex mantissa * 2^e
   float2 m;
@@ -1324,9 +1324,9 @@ struct SharedR {
   Prod carry[2];
 };
 
-__device__ __forceinline__ int rpad16(int q) { return q + (q >> 4); }
+__device__ __forceinline__ int rpad16(int q) { return q + q / E; }  // lane stride E + 1 entries
 // staged slot q0 + d of a lane whose first slot q0 is a multiple of 16: base + roff(d), d a compile-time constant
-__device__ __forceinline__ constexpr int roff(int d) { return d + (d >= 0 ? d / 16 : -((15 - d) / 16)); }
+__device__ __forceinline__ constexpr int roff(int d) { return d + (d >= 0 ? d / E : -((E - 1 - d) / E)); }
 
 // A lane's 16 consecutive complex values as eight 16-byte stores (the struct is only 4-byte aligned: rows start
 // anywhere); `count` < 16 only at the ragged end of a row.
