@@ -11,6 +11,12 @@ forward signatures on top of the HIP operator.
                               recurrence in its own CUDA kernels and clamps Re/Im to +-10; here the numbers come from
                               the HIP operator (regularised, soft-clamped: the semantics of bk_core.py) followed by the
                               same +-10 clamp, so results agree to the regularisation's 1e-3 on well-conditioned input.
+  * ``LearnedTridiagonalGreen`` the Green-function step of the reference's hyperbolic BK-Core block
+                              (src/models/phase8/bk_core_hyperbolic.py:282-286, 349-407): all three diagonals are
+                              projections of the input (``he_diag_proj``, ``h0_super_proj``, ``h0_sub_proj``, same names and
+                              initialisation), bf16 operands, ``BKCoreFunction.apply(he_diag, h0_super, h0_sub, z, False)``.
+                              In the reference the off-diagonal projections never receive a gradient (the operator
+                              returns None for them); with ``BKCoreFunction.GRAD_MODE = "analytic"`` they do.
 """
 from __future__ import annotations
 
@@ -88,3 +94,31 @@ class CUDAOptimizedBKCore(nn.Module):
         features, _ = BKCoreFunction.apply(he_diag.float(), self.h0_super.unsqueeze(0).expand(B, -1),
                                            self.h0_sub.unsqueeze(0).expand(B, -1), complex(self.z))
         return torch.clamp(features, -10.0, 10.0)
+
+
+class LearnedTridiagonalGreen(nn.Module):
+    def __init__(self, d_model: int, z_real: float = 0.0, z_imag: float = 0.1):
+        super().__init__()
+        self.he_diag_proj = nn.Linear(d_model, d_model)
+        self.h0_super_proj = nn.Linear(d_model, d_model)
+        self.h0_sub_proj = nn.Linear(d_model, d_model)
+        self.register_buffer("z", torch.complex(torch.tensor(z_real), torch.tensor(z_imag)))
+        # identity start: diagonal 1, off-diagonals 0, weights ~ N(0, 1e-4) (bk_core_hyperbolic.py:349-365)
+        nn.init.normal_(self.he_diag_proj.weight, mean=0.0, std=1e-4)
+        nn.init.constant_(self.he_diag_proj.bias, 1.0)
+        for proj in (self.h0_super_proj, self.h0_sub_proj):
+            nn.init.normal_(proj.weight, mean=0.0, std=1e-4)
+            nn.init.zeros_(proj.bias)
+
+    def compute_green_function(self, x: torch.Tensor):
+        """x (B, N, D) -> (G_ii (B, N) complex64, features (B, N, 2) float32)."""
+        xb = x.to(torch.bfloat16)
+        w = lambda proj: (proj.weight.to(torch.bfloat16), proj.bias.to(torch.bfloat16))
+        he_diag = F.linear(xb, *w(self.he_diag_proj)).mean(dim=-1)
+        h0_super = F.linear(xb[:, :-1], *w(self.h0_super_proj)).mean(dim=-1)
+        h0_sub = F.linear(xb[:, 1:], *w(self.h0_sub_proj)).mean(dim=-1)
+        features, G_ii = BKCoreFunction.apply(he_diag, h0_super, h0_sub, self.z.to(x.device), False)
+        return G_ii, features
+
+    def forward(self, x: torch.Tensor):
+        return self.compute_green_function(x)

@@ -88,3 +88,65 @@ def test_cuda_optimized_bk_core_signature():
     ref = torch.stack([Gd.real, Gd.imag], -1).float()
     # un-regularised resolvent vs the operator's regularised one: 1e-3 (the reference's own bound, tests/test_bk_core.py:47-77)
     np.testing.assert_allclose(feats.cpu().numpy(), ref.numpy(), atol=2e-3)
+
+
+def test_learned_tridiagonal_green_names():
+    import bkcore
+    m = bkcore.LearnedTridiagonalGreen(d_model=8)
+    assert set(m.state_dict().keys()) == {"he_diag_proj.weight", "he_diag_proj.bias", "h0_super_proj.weight",
+                                          "h0_super_proj.bias", "h0_sub_proj.weight", "h0_sub_proj.bias", "z"}
+    assert torch.all(m.he_diag_proj.bias == 1.0) and torch.all(m.h0_sub_proj.bias == 0.0)
+    assert m.z == complex(0.0, 0.1)
+
+
+@pytest.mark.gpu
+def test_learned_offdiagonals_receive_gradients_in_analytic_mode():
+    """The hyperbolic block's Green-function step (reference phase8/bk_core_hyperbolic.py:367-407) with position-varying
+    learned b != c.  Reference mode: no gradient reaches the off-diagonal projections (bk_core.py:384-385).  Analytic
+    mode: they get the gradient of the forward; checked against the float64 adjoint specification for d/d he_diag,
+    d/d h0_super, d/d h0_sub on the operator's own (bf16-rounded) operands."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import bkcore
+    from oracle.bk_analytic_adjoint import adjoint_grads
+    torch.manual_seed(2)
+    B, N, D = 2, 96, 8
+    m = bkcore.LearnedTridiagonalGreen(D, z_imag=0.6).cuda()
+    with torch.no_grad():
+        m.he_diag_proj.weight.normal_(0.0, 0.2)
+        m.h0_super_proj.weight.normal_(0.0, 0.2); m.h0_super_proj.bias.fill_(0.5)
+        m.h0_sub_proj.weight.normal_(0.0, 0.2); m.h0_sub_proj.bias.fill_(0.7)
+    x = torch.randn(B, N, D, device="cuda")
+    gf = torch.randn(B, N, 2, device="cuda")
+
+    G, feats = m(x)
+    (feats * gf).sum().backward()
+    assert m.he_diag_proj.weight.grad is not None
+    assert m.h0_super_proj.weight.grad is None and m.h0_sub_proj.weight.grad is None     # reference behaviour
+
+    m.zero_grad(set_to_none=True)
+    bkcore.BKCoreFunction.GRAD_MODE = "analytic"
+    try:
+        captured = {}
+        orig = bkcore.BKCoreFunction.apply
+
+        def spy(a, b, c, z, *rest):                               # keep the operands to differentiate them directly
+            a.retain_grad(); b.retain_grad(); c.retain_grad()
+            captured.update(a=a, b=b, c=c)
+            return orig(a, b, c, z, *rest)
+        bkcore.layers.BKCoreFunction.apply, saved = spy, bkcore.layers.BKCoreFunction.apply
+        try:
+            G, feats = m(x)
+            (feats * gf).sum().backward()
+        finally:
+            bkcore.layers.BKCoreFunction.apply = saved
+    finally:
+        bkcore.BKCoreFunction.GRAD_MODE = "reference"
+    for proj in (m.he_diag_proj, m.h0_super_proj, m.h0_sub_proj):
+        assert proj.weight.grad is not None and torch.isfinite(proj.weight.grad).all() and proj.weight.grad.abs().max() > 0
+    a, b, c = (captured[k].detach().double().cpu().numpy() for k in "abc")
+    gbar = torch.complex(gf[..., 0], gf[..., 1]).to(torch.complex128).cpu().numpy()
+    ra, rb, rc, _ = adjoint_grads(a, b, c, complex(0.0, 0.6), gbar, "reference")
+    for got, ref in ((captured["a"].grad, ra), (captured["b"].grad, rb), (captured["c"].grad, rc)):
+        got = got.double().cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-2 * np.abs(ref).max()   # the operand gradients are rounded to bf16 (2^-8)
