@@ -1274,6 +1274,10 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_split_output_kernel(
 #define BK_RATIO_WAVES 2
 #endif
 constexpr int RH = 16;                          // warm-up length = halo staged on both sides of a chunk
+#ifndef BK_RH_COARSE
+#define BK_RH_COARSE 8
+#endif
+constexpr int RH_COARSE = BK_RH_COARSE;         // leading warm-up steps taken in the coarse form
 constexpr int RN = CHUNK + 2 * RH;              // staged elements per chunk
 constexpr int RAL_PAD = RN + RN / E + 8;        // float2 entries, index q + q/E
 constexpr int RK_PAD = RN + 1 + (RN + 1) / E + 8;
@@ -1372,6 +1376,14 @@ __device__ __forceinline__ float2 ratio_step(float2 al, float k, float2 om, floa
   const float g = (u * s2) * p;
   const float wc = fmaf(g, fmaf(g, 0.5f, 1.0f), 1.0f);
   return make_float2(inv.x * wc, inv.y * wc);
+}
+
+// The same step without the Newton refinement and without the clamp factor (a relative 1e-4 at most for |r| within
+// e^+-2 of 1): for the first warm-up steps, whose errors the remaining ones contract away.
+__device__ __forceinline__ float2 ratio_step_coarse(float2 al, float k, float2 om) {
+  const float2 r = make_float2(fmaf(-k, om.x, al.x), fmaf(-k, om.y, al.y));
+  const float y = __builtin_amdgcn_rcpf(fmaf(r.x, r.x, r.y * r.y));
+  return make_float2(r.x * y, -r.y * y);
 }
 
 // |p - q| > 2e-6 |q| (also true when anything is not a number; false when both are zero)
@@ -1548,9 +1560,14 @@ __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
     float2 wt = make_float2(0.f, 0.f), wp = make_float2(0.f, 0.f), r, inv;
 #pragma unroll
     for (int j = 0; j < RH; ++j) {
-      wt = ratio_step(al_l[roff(j - RH)], k_l[roff(j - RH)], wt, r, inv);
       const int d = E + RH - 1 - j;
-      wp = ratio_step(al_l[roff(d)], k_l[roff(d + KO)], wp, r, inv);
+      if (j < RH_COARSE) {
+        wt = ratio_step_coarse(al_l[roff(j - RH)], k_l[roff(j - RH)], wt);
+        wp = ratio_step_coarse(al_l[roff(d)], k_l[roff(d + KO)], wp);
+      } else {
+        wt = ratio_step(al_l[roff(j - RH)], k_l[roff(j - RH)], wt, r, inv);
+        wp = ratio_step(al_l[roff(d)], k_l[roff(d + KO)], wp, r, inv);
+      }
       if (TAIL && i0 + d >= N) wp = make_float2(0.f, 0.f);
     }
     const float2 th_west = wt, ph_west = wp;
