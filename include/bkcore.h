@@ -120,6 +120,31 @@ int bkcore_backward_analytic(const float *a, int64_t lda, const float *b, int64_
                              void *stream);
 size_t bkcore_backward_analytic_workspace_bytes(int64_t B, int64_t N);
 
+/*
+ * The caller's elementwise steps in front of the operator, in one pass: replaces the tensor-library chain of
+ * MoEResNetBKLayer.forward, src/models/resnet_bk.py:139-141 (nan_to_num(v, 0, +v_max, -v_max); v_max * tanh(v / v_max)),
+ * :158 (he_diag = h0_diag + v) and :165 (cast to bfloat16).
+ *
+ * v_pre: B rows of N floats (the output of v_proj), row stride ldv; h0_diag: N floats (one row, broadcast over B);
+ * he_diag: B*N contiguous elements of out_dtype (BKCORE_BF16: round to nearest even; or BKCORE_F32).
+ */
+int bkcore_layer_prologue(const float *v_pre, int64_t ldv, const float *h0_diag, float v_max, int64_t B, int64_t N,
+                          void *he_diag, int out_dtype, void *stream);
+
+/*
+ * Backward of the same chain fused with bkcore_backward_ref: gradient with respect to v_pre given the cotangents of the
+ * CLAMPED features (clamp(features, -feature_clamp, feature_clamp), src/models/resnet_bk.py:216-217) and of G.
+ * Replaces, in one pass over n = B*N elements: the clamp's backward, BKCoreFunction.backward
+ * (src/models/bk_core.py:303-385), the autograd engine's cast of that float32 gradient to the bfloat16 operand's dtype
+ * (round_bf16 != 0), and the backward of the tanh / nan_to_num chain.
+ *
+ * G: n complex64 saved by forward; grad_features: n*2 floats or NULL; grad_G: n complex64 or NULL;
+ * feature_clamp <= 0: no clamp; v_pre: n contiguous floats as given to bkcore_layer_prologue; grad_v: n floats.
+ */
+int bkcore_layer_backward_ref(const float *G, const float *grad_features, const float *grad_G, float alpha,
+                              float feature_clamp, const float *v_pre, float v_max, int round_bf16, int64_t n,
+                              float *grad_v, void *stream);
+
 /* Largest N bkcore_forward accepts. */
 int64_t bkcore_max_seq_len(void);
 /* HIP error code of the last failed launch on this thread (0 if none). */

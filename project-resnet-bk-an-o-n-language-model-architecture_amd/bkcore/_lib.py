@@ -14,11 +14,12 @@ FLAG_RAW = 1
 FLAG_PHI_EXACT = 2
 FLAG_SCAN_PATH = 4
 STATE_BYTES = 64
-ABI_VERSION = 4
+ABI_VERSION = 5
 EINVAL, ETOOLONG, ELAUNCH, EWORKSPACE = -1, -2, -3, -4
 
 EXPORTS = ("bkcore_forward", "bkcore_workspace_bytes", "bkcore_backward_ref", "bkcore_backward_analytic",
-           "bkcore_backward_analytic_workspace_bytes", "bkcore_max_seq_len", "bkcore_last_hip_error",
+           "bkcore_backward_analytic_workspace_bytes", "bkcore_layer_prologue", "bkcore_layer_backward_ref",
+           "bkcore_max_seq_len", "bkcore_last_hip_error",
            "bkcore_error_string", "bkcore_abi_version")
 
 _lib = None
@@ -46,6 +47,10 @@ def load():
     L.bkcore_backward_analytic.restype = i32
     L.bkcore_backward_analytic_workspace_bytes.argtypes = [i64, i64]
     L.bkcore_backward_analytic_workspace_bytes.restype = ctypes.c_size_t
+    L.bkcore_layer_prologue.argtypes = [vp, i64, vp, f32, i64, i64, vp, i32, vp]
+    L.bkcore_layer_prologue.restype = i32
+    L.bkcore_layer_backward_ref.argtypes = [vp, vp, vp, f32, f32, vp, f32, i32, i64, vp, vp]
+    L.bkcore_layer_backward_ref.restype = i32
     L.bkcore_max_seq_len.restype = i64
     L.bkcore_last_hip_error.restype = i32
     L.bkcore_error_string.argtypes = [i32]

@@ -158,6 +158,61 @@ def bk_backward_reference(G, grad_features, grad_G, alpha: float):
     return out
 
 
+
+def layer_prologue(v_pre, h0_diag, v_max: float, out_dtype=torch.bfloat16):
+    """he_diag = h0_diag + v_max * tanh(nan_to_num(v_pre, 0, +-v_max) / v_max), cast to ``out_dtype``, in one launch
+    (the elementwise chain of reference src/models/resnet_bk.py:139-141,158,165).  v_pre (B, N) float32 on the GPU,
+    h0_diag N floats (any shape with N elements)."""
+    L = _lib.load()
+    if not v_pre.is_cuda:
+        raise RuntimeError("bkcore: tensors must be on a ROCm device (no CPU path)")
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError("bkcore: layer_prologue writes bfloat16 or float32")
+    if v_pre.dim() != 2:
+        raise ValueError(f"bkcore: v_pre must have shape (B, N), got {tuple(v_pre.shape)}")
+    B, N = v_pre.shape
+    v = v_pre if v_pre.dtype == torch.float32 else v_pre.float()
+    if N > 1 and v.stride(1) != 1 or v.stride(0) < 0:
+        v = v.contiguous()
+    h0 = h0_diag.reshape(-1).to(device=v.device, dtype=torch.float32).contiguous()
+    if h0.numel() != N:
+        raise ValueError(f"bkcore: h0_diag must hold N = {N} values, got {h0.numel()}")
+    out = torch.empty((B, N), dtype=out_dtype, device=v.device)
+    if B == 0 or N == 0:
+        return out
+    with torch.cuda.device(v.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = L.bkcore_layer_prologue(v.data_ptr(), v.stride(0) if B > 1 else N, h0.data_ptr(), float(v_max), B, N,
+                                     out.data_ptr(), _lib.BF16 if out_dtype == torch.bfloat16 else _lib.F32, stream)
+    _lib.check(rc, "bkcore_layer_prologue")
+    return out
+
+
+def layer_backward_reference(G, grad_features, grad_G, alpha: float, feature_clamp, v_pre, v_max: float,
+                             round_bf16: bool = True):
+    """Gradient with respect to v_pre through clamp(features) -> operator (reference-mode backward) -> bfloat16 cast
+    -> tanh saturation -> nan_to_num, in one launch.  Returns float32 with v_pre's shape."""
+    L = _lib.load()
+    G = G.contiguous()
+    v = v_pre.float().contiguous()
+    if v.numel() != G.numel():
+        raise ValueError("bkcore: v_pre and G must hold the same number of elements")
+    out = torch.empty(v.shape, dtype=torch.float32, device=G.device)
+    n = G.numel()
+    if n == 0:
+        return out
+    gf = grad_features.float().contiguous() if grad_features is not None else None
+    gg = grad_G.to(torch.complex64).contiguous() if grad_G is not None else None
+    with torch.cuda.device(G.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = L.bkcore_layer_backward_ref(G.data_ptr(), gf.data_ptr() if gf is not None else None,
+                                         gg.data_ptr() if gg is not None else None, float(alpha),
+                                         float(feature_clamp) if feature_clamp is not None else 0.0, v.data_ptr(),
+                                         float(v_max), 1 if round_bf16 else 0, n, out.data_ptr(), stream)
+    _lib.check(rc, "bkcore_layer_backward_ref")
+    return out
+
+
 def sanitise_inputs(he_diag, h0_super, h0_sub):
     """float32 copies of the operands after the operator's input clamp and conditional NaN replacement
     (reference bk_core.py:256-264), plus the masks of elements the clamp left untouched (where the gradient
@@ -307,6 +362,51 @@ class BKCoreFunction(torch.autograd.Function):
         (G,) = ctx.saved_tensors
         grad = bk_backward_reference(G, grad_output_features, grad_G_ii, BKCoreFunction.GRAD_BLEND)
         return grad, None, None, None, None, None
+
+
+class FusedBKLayerFunction(torch.autograd.Function):
+    """The BK-Core branch of the reference layer from the output of ``v_proj`` to the clamped features
+    (src/models/resnet_bk.py:139-170, 216-217) with its elementwise steps fused into two launches around the operator:
+
+        apply(v_pre (B,N) f32, h0_diag (N), h0_super, h0_sub (B|1, N-1), z, v_max, feature_clamp|None)
+            -> (clamp(features) (B,N,2) f32, G_ii (B,N) complex64)
+
+    Forward: one prologue launch (nan_to_num, tanh saturation, + h0_diag, bfloat16), the operator on bfloat16
+    operands, the clamp in place.  Backward: one launch for the whole chain (reference-mode gradient only; the
+    gradient reaches ``v_pre`` alone, as in the reference where the off-diagonals are buffers).  ``GRAD_BLEND`` and
+    ``PHI_K_INDEX`` are read from ``BKCoreFunction``."""
+
+    @staticmethod
+    def forward(ctx, v_pre, h0_diag, h0_super, h0_sub, z, v_max, feature_clamp):
+        if BKCoreFunction.GRAD_MODE != "reference":
+            raise RuntimeError("bkcore: FusedBKLayerFunction implements the reference-mode gradient only")
+        B, N = v_pre.shape
+        v = v_pre.detach().float().contiguous()
+        he = layer_prologue(v, h0_diag.detach(), v_max, torch.bfloat16)
+        nb = max(N - 1, 0)
+        b = h0_super.detach().to(torch.bfloat16).reshape(-1, nb)
+        c = h0_sub.detach().to(torch.bfloat16).reshape(-1, nb)
+        if b.shape[0] != B:
+            b = b.expand(B, -1)
+        if c.shape[0] != B:
+            c = c.expand(B, -1)
+        feats, G = bk_forward(he, b, c, z, raw=False, phi_exact=(BKCoreFunction.PHI_K_INDEX == "exact"))
+        if feature_clamp is not None:
+            feats.clamp_(-float(feature_clamp), float(feature_clamp))
+        ctx.set_materialize_grads(False)
+        ctx.bk_v_max = float(v_max)
+        ctx.bk_clamp = feature_clamp
+        ctx.save_for_backward(G, v)
+        return feats, G
+
+    @staticmethod
+    def backward(ctx, grad_features, grad_G_ii):
+        if grad_features is None and grad_G_ii is None:
+            return (None,) * 7
+        G, v = ctx.saved_tensors
+        grad_v = layer_backward_reference(G, grad_features, grad_G_ii, BKCoreFunction.GRAD_BLEND, ctx.bk_clamp, v,
+                                          ctx.bk_v_max, round_bf16=True)
+        return grad_v, None, None, None, None, None, None
 
 
 def set_triton_mode(enabled: bool):

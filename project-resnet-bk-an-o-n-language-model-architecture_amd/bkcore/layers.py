@@ -24,12 +24,16 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .bk_core import BKCoreFunction
+from .bk_core import BKCoreFunction, FusedBKLayerFunction
 
 
 class BKCoreLayer(nn.Module):
-    def __init__(self, d_model: int, n_seq: int, v_max: float = 5.0, feature_clamp: float | None = 5.0):
+    def __init__(self, d_model: int, n_seq: int, v_max: float = 5.0, feature_clamp: float | None = 5.0,
+                 fused: bool = False):
         super().__init__()
+        # fused: run the elementwise steps between v_proj and output_proj inside the library (two launches around the
+        # operator instead of about a dozen tensor-library kernels per direction); same numbers as the unfused chain
+        self.fused = fused
         self.d_model = d_model
         self.n_seq = n_seq
         self.v_proj = nn.Linear(d_model, 1)
@@ -50,11 +54,20 @@ class BKCoreLayer(nn.Module):
         self.last_g_ii = None
 
     def spectral_features(self, x: torch.Tensor):
-        """x (B, N, D) -> (features (B, N, 2) float32, G_ii (B, N, 1) complex64)."""
+        """x (B, N, D) -> (features (B, N, 2) float32, G_ii (B, N, 1) complex64).  With ``fused`` the features are
+        already clamped to +-feature_clamp."""
         B, N, _ = x.shape
         if N != self.n_seq:
             raise ValueError(f"Sequence length mismatch: expected {self.n_seq}, got {N}")
         v = self.v_proj(x).squeeze(-1)
+        if self._use_fused():
+            epsilon = F.softplus(self.epsilon_param) + 1e-4
+            z = (1.0j * epsilon + 1j * self.gamma).to(dtype=torch.complex64, device=v.device)
+            features, g = FusedBKLayerFunction.apply(v, self.h0_diag_base, self.h0_super_base, self.h0_sub_base, z,
+                                                     self.v_max, self.feature_clamp)
+            G_ii = g.unsqueeze(-1)          # the operator maps non-finite values to 0: nothing to replace
+            self.last_g_ii = G_ii
+            return features, G_ii
         v = torch.nan_to_num(v, nan=0.0, posinf=self.v_max, neginf=-self.v_max)
         v = self.v_max * torch.tanh(v / self.v_max)
         he_diag = self.h0_diag_base.expand(B, -1) + v
@@ -69,10 +82,13 @@ class BKCoreLayer(nn.Module):
         self.last_g_ii = G_ii
         return features, G_ii
 
+    def _use_fused(self) -> bool:
+        return (self.fused and self.bk_core == BKCoreFunction.apply and BKCoreFunction.GRAD_MODE == "reference")
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """The layer's spectral branch: bk_scale * output_proj(clamp(features)) (resnet_bk.py:216-219)."""
         features, _ = self.spectral_features(x)
-        if self.feature_clamp is not None:
+        if self.feature_clamp is not None and not self._use_fused():   # the fused path returns clamped features
             features = torch.clamp(features, -self.feature_clamp, self.feature_clamp)
         return self.bk_scale * self.output_proj(features)
 

@@ -17,10 +17,10 @@ from .layers import BKCoreLayer
 
 
 class ResNetBKBlock(nn.Module):
-    def __init__(self, d_model: int, n_seq: int, ffn_mult: int = 4):
+    def __init__(self, d_model: int, n_seq: int, ffn_mult: int = 4, fused: bool = False):
         super().__init__()
         self.layer_norm = nn.LayerNorm(d_model)
-        self.bk_layer = BKCoreLayer(d_model, n_seq)
+        self.bk_layer = BKCoreLayer(d_model, n_seq, fused=fused)
         self.ffn = nn.Sequential(nn.Linear(d_model, ffn_mult * d_model), nn.GELU(), nn.Linear(ffn_mult * d_model, d_model))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -29,12 +29,13 @@ class ResNetBKBlock(nn.Module):
 
 
 class SmallResNetBKLM(nn.Module):
-    def __init__(self, vocab_size: int = 50257, d_model: int = 256, n_layers: int = 4, n_seq: int = 256):
+    def __init__(self, vocab_size: int = 50257, d_model: int = 256, n_layers: int = 4, n_seq: int = 256,
+                 fused: bool = False):
         super().__init__()
         self.n_seq = n_seq
         self.token_embedding = nn.Embedding(vocab_size, d_model)
         self.position_embedding = nn.Embedding(n_seq, d_model)
-        self.blocks = nn.ModuleList([ResNetBKBlock(d_model, n_seq) for _ in range(n_layers)])
+        self.blocks = nn.ModuleList([ResNetBKBlock(d_model, n_seq, fused=fused) for _ in range(n_layers)])
         self.layer_norm_final = nn.LayerNorm(d_model)
         self.lm_head = nn.Linear(d_model, vocab_size)
         nn.init.normal_(self.token_embedding.weight, std=0.02)

@@ -1869,6 +1869,76 @@ __global__ __launch_bounds__(256) void bk_backward_ref_kernel(const float2 *__re
   }
 }
 
+// ---- the caller's elementwise steps around the operator (resnet_bk.py:137-167, 216-217) ------------------------
+// Prologue: v -> nan_to_num(v, 0, +-v_max) -> v_max tanh(v / v_max) -> h0_diag + v -> bfloat16 (round to nearest
+// even) or float32.  The division is a multiplication by the rounded reciprocal, as the tensor library evaluates a
+// division by a scalar on the device.
+__device__ __forceinline__ float saturate_potential(float v, float v_max, float inv_v_max) {
+  if (v != v) v = 0.0f;
+  else if (v > 3.4028234663852886e38f) v = v_max;
+  else if (v < -3.4028234663852886e38f) v = -v_max;
+  return v_max * tanhf(v * inv_v_max);
+}
+__device__ __forceinline__ uint16_t to_bf16_rne(float x) {
+  const unsigned u = __float_as_uint(x);
+  if (x != x) return (uint16_t)0x7FC0u;
+  return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_round(float x) { return __uint_as_float((unsigned)to_bf16_rne(x) << 16); }
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void bk_layer_prologue_kernel(const float *__restrict__ v_pre, long ldv,
+                                                                const float *__restrict__ h0_diag, float v_max,
+                                                                float inv_v_max, long B, long N,
+                                                                void *__restrict__ he_diag) {
+  for (long row = blockIdx.y; row < B; row += gridDim.y) {
+    const float *__restrict__ v = v_pre + row * ldv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+      const float he = h0_diag[i] + saturate_potential(v[i], v_max, inv_v_max);
+      if (OUT_BF16) reinterpret_cast<uint16_t *>(he_diag)[row * N + i] = to_bf16_rne(he);
+      else reinterpret_cast<float *>(he_diag)[row * N + i] = he;
+    }
+  }
+}
+
+// Backward of the same chain in one pass: clamp mask on the features (the features are Re G and Im G, so the mask is
+// recomputed from G), the operator's reference-mode gradient, its rounding to bfloat16 (what the autograd engine does
+// to a float32 gradient of a bfloat16 operand), the tanh saturation and the nan_to_num mask.
+template <bool HAS_GF, bool HAS_GG>
+__global__ __launch_bounds__(256) void bk_layer_backward_ref_kernel(const float2 *__restrict__ G,
+                                                                    const float2 *__restrict__ gf,
+                                                                    const float2 *__restrict__ gG, float alpha,
+                                                                    float fclamp, const float *__restrict__ v_pre,
+                                                                    float v_max, float inv_v_max, int round_bf16, long n,
+                                                                    float *__restrict__ out) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float2 Gv = G[i];
+    float2 g = make_float2(0.f, 0.f);
+    if (HAS_GF) {
+      g = gf[i];
+      if (!(fabsf(Gv.x) <= fclamp)) g.x = 0.0f;   // clamp passes the gradient on [-fclamp, fclamp] only
+      if (!(fabsf(Gv.y) <= fclamp)) g.y = 0.0f;
+      g.x = nan_to_num_default(g.x);
+      g.y = nan_to_num_default(g.y);
+    }
+    if (HAS_GG) {
+      const float2 q = gG[i];
+      g.x += q.x;
+      g.y += q.y;
+    }
+    float ga = bwd_ref_one(Gv, g, alpha);
+    if (round_bf16) ga = bf16_round(ga);
+    const float v = v_pre[i];
+    float gv = 0.0f;
+    if (fabsf(v) <= 3.4028234663852886e38f) {       // nan_to_num passes the gradient of finite entries only
+      const float th = tanhf(v * inv_v_max);
+      gv = ((ga * v_max) * (1.0f - th * th)) * inv_v_max;
+    }
+    __builtin_nontemporal_store(gv, &out[i]);
+  }
+}
+
 thread_local int g_last_hip_error = 0;
 int g_call_counter = 0;
 
@@ -2081,9 +2151,63 @@ int bkcore_backward_ref(const float *G, const float *grad_features, const float 
   return BKCORE_OK;
 }
 
+int bkcore_layer_prologue(const float *v_pre, int64_t ldv, const float *h0_diag, float v_max, int64_t B, int64_t N,
+                          void *he_diag, int out_dtype, void *stream) {
+  if (B < 0 || N < 0 || ldv < 0 || !(v_max > 0.0f)) return BKCORE_EINVAL;
+  if (out_dtype != BKCORE_BF16 && out_dtype != BKCORE_F32) return BKCORE_EINVAL;
+  if (B == 0 || N == 0) return BKCORE_OK;
+  if (!v_pre || !h0_diag || !he_diag) return BKCORE_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  long gx = (N + 1023) / 1024;
+  if (gx > 1024) gx = 1024;
+  const dim3 grid((unsigned)gx, (unsigned)(B > 32768 ? 32768 : B)), block(256);
+  const float inv = 1.0f / v_max;
+  if (out_dtype == BKCORE_BF16)
+    hipLaunchKernelGGL((bk_layer_prologue_kernel<true>), grid, block, 0, s, v_pre, (long)ldv, h0_diag, v_max, inv,
+                       (long)B, (long)N, he_diag);
+  else
+    hipLaunchKernelGGL((bk_layer_prologue_kernel<false>), grid, block, 0, s, v_pre, (long)ldv, h0_diag, v_max, inv,
+                       (long)B, (long)N, he_diag);
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    g_last_hip_error = (int)err;
+    return BKCORE_ELAUNCH;
+  }
+  return BKCORE_OK;
+}
+
+int bkcore_layer_backward_ref(const float *G, const float *grad_features, const float *grad_G, float alpha,
+                              float feature_clamp, const float *v_pre, float v_max, int round_bf16, int64_t n,
+                              float *grad_v, void *stream) {
+  if (n < 0 || !(v_max > 0.0f)) return BKCORE_EINVAL;
+  if (n == 0) return BKCORE_OK;
+  if (!G || !v_pre || !grad_v) return BKCORE_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const float fc = feature_clamp > 0.0f ? feature_clamp : __builtin_huge_valf();
+  long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  const dim3 grid((unsigned)blocks), block(256);
+  const float inv = 1.0f / v_max;
+  const float2 *Gp = (const float2 *)G, *gf = (const float2 *)grad_features, *gg = (const float2 *)grad_G;
+#define BK_LB(GF, GG)                                                                                                \
+  hipLaunchKernelGGL((bk_layer_backward_ref_kernel<GF, GG>), grid, block, 0, s, Gp, gf, gg, alpha, fc, v_pre, v_max, \
+                     inv, round_bf16, (long)n, grad_v)
+  if (gf && gg) BK_LB(true, true);
+  else if (gf) BK_LB(true, false);
+  else if (gg) BK_LB(false, true);
+  else BK_LB(false, false);
+#undef BK_LB
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    g_last_hip_error = (int)err;
+    return BKCORE_ELAUNCH;
+  }
+  return BKCORE_OK;
+}
+
 int64_t bkcore_max_seq_len(void) { return (int64_t)MAX_N; }
 int bkcore_last_hip_error(void) { return g_last_hip_error; }
-int bkcore_abi_version(void) { return 4; }
+int bkcore_abi_version(void) { return 5; }
 
 const char *bkcore_error_string(int code) {
   switch (code) {

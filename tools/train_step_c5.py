@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--fused", action="store_true", help="elementwise steps around the operator inside the library")
     args = ap.parse_args()
     rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -29,7 +30,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
     from bkcore.lm import SmallResNetBKLM, training_step
     torch.manual_seed(0)
-    model = SmallResNetBKLM().to(device)
+    model = SmallResNetBKLM(fused=args.fused).to(device)
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index])
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01)
@@ -56,7 +57,7 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "resnet_bk_small_lm_train_tokens_per_sec", "value": world * args.batch * n_seq * args.steps / dt,
                           "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
-                          "final_loss": float(loss), "config": {"workload": "phase7_small dims: d_model 256, 4 layers, n_seq 256, "
+                          "final_loss": float(loss), "fused_layer": bool(args.fused), "config": {"workload": "phase7_small dims: d_model 256, 4 layers, n_seq 256, "
                           f"batch {args.batch}/GPU, vocab 50257, AdamW 1e-4, clip 1.0; dummy tokens", "parallelism": f"dp{world}"}}))
     if world > 1:
         dist.destroy_process_group()
