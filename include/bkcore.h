@@ -121,6 +121,17 @@ int bkcore_backward_analytic(const float *a, int64_t lda, const float *b, int64_
 size_t bkcore_backward_analytic_workspace_bytes(int64_t B, int64_t N);
 
 /*
+ * bkcore_forward with the caller's clamp of the features folded into the store: features = clamp((Re G, Im G),
+ * -feature_clamp, feature_clamp) as MoEResNetBKLayer.forward applies after the operator
+ * (src/models/resnet_bk.py:216-217); G itself is written unclamped.  feature_clamp <= 0: no clamp (identical to
+ * bkcore_forward).  All other arguments as in bkcore_forward.
+ */
+int bkcore_forward_clamped(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
+                           int in_dtype, const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G,
+                           float *features, float feature_clamp, void *workspace, size_t workspace_bytes, void *state,
+                           unsigned flags, void *stream);
+
+/*
  * The caller's elementwise steps in front of the operator, in one pass: replaces the tensor-library chain of
  * MoEResNetBKLayer.forward, src/models/resnet_bk.py:139-141 (nan_to_num(v, 0, +v_max, -v_max); v_max * tanh(v / v_max)),
  * :158 (he_diag = h0_diag + v) and :165 (cast to bfloat16).

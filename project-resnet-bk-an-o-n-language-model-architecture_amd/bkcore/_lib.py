@@ -14,10 +14,10 @@ FLAG_RAW = 1
 FLAG_PHI_EXACT = 2
 FLAG_SCAN_PATH = 4
 STATE_BYTES = 64
-ABI_VERSION = 5
+ABI_VERSION = 6
 EINVAL, ETOOLONG, ELAUNCH, EWORKSPACE = -1, -2, -3, -4
 
-EXPORTS = ("bkcore_forward", "bkcore_workspace_bytes", "bkcore_backward_ref", "bkcore_backward_analytic",
+EXPORTS = ("bkcore_forward", "bkcore_forward_clamped", "bkcore_workspace_bytes", "bkcore_backward_ref", "bkcore_backward_analytic",
            "bkcore_backward_analytic_workspace_bytes", "bkcore_layer_prologue", "bkcore_layer_backward_ref",
            "bkcore_max_seq_len", "bkcore_last_hip_error",
            "bkcore_error_string", "bkcore_abi_version")
@@ -37,6 +37,9 @@ def load():
     vp, i64, i32, f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
     L.bkcore_forward.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp, f32, f32, i64, i64, vp, vp, vp, ctypes.c_size_t,
                                  vp, ctypes.c_uint, vp]
+    L.bkcore_forward_clamped.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp, f32, f32, i64, i64, vp, vp, f32, vp,
+                                         ctypes.c_size_t, vp, ctypes.c_uint, vp]
+    L.bkcore_forward_clamped.restype = i32
     L.bkcore_workspace_bytes.argtypes = [i64, i64]
     L.bkcore_workspace_bytes.restype = ctypes.c_size_t
     L.bkcore_forward.restype = i32

@@ -89,8 +89,10 @@ def _prep_z(z, device):
     return None, None, float(zc.real), float(zc.imag)
 
 
-def bk_forward(a, b, c, z, raw: bool = False, phi_exact: bool = False, want_features: bool = True):
-    """Launch the HIP forward.  a (B,N), b/c (B,N-1) real tensors on the GPU.  Returns (features|None, G)."""
+def bk_forward(a, b, c, z, raw: bool = False, phi_exact: bool = False, want_features: bool = True,
+               feature_clamp=None):
+    """Launch the HIP forward.  a (B,N), b/c (B,N-1) real tensors on the GPU.  Returns (features|None, G).
+    feature_clamp: the features come out clamped to +-feature_clamp (G does not)."""
     L = _lib.load()
     a, b, c, dt = _prep_inputs(a, b, c)
     B, N = a.shape
@@ -110,10 +112,18 @@ def bk_forward(a, b, c, z, raw: bool = False, phi_exact: bool = False, want_feat
             | (_lib.FLAG_SCAN_PATH if _DEBUG["scan_path"] else 0)
         ws_bytes = int(L.bkcore_workspace_bytes(B, N))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
-        rc = L.bkcore_forward(pa, lda, pb if nb else None, ldb, pc if nb else None, ldc, dt, pz, zre, zim, B, N,
-                              G.data_ptr(), feats.data_ptr() if feats is not None else None,
-                              ws.data_ptr() if ws is not None else None, ws_bytes,
-                              state.data_ptr() if state is not None else None, flags, stream)
+        if feature_clamp is None:
+            rc = L.bkcore_forward(pa, lda, pb if nb else None, ldb, pc if nb else None, ldc, dt, pz, zre, zim, B, N,
+                                  G.data_ptr(), feats.data_ptr() if feats is not None else None,
+                                  ws.data_ptr() if ws is not None else None, ws_bytes,
+                                  state.data_ptr() if state is not None else None, flags, stream)
+        else:
+            if not float(feature_clamp) > 0.0:
+                raise ValueError("bkcore: feature_clamp must be positive")
+            rc = L.bkcore_forward_clamped(pa, lda, pb if nb else None, ldb, pc if nb else None, ldc, dt, pz, zre, zim,
+                                          B, N, G.data_ptr(), feats.data_ptr() if feats is not None else None,
+                                          float(feature_clamp), ws.data_ptr() if ws is not None else None, ws_bytes,
+                                          state.data_ptr() if state is not None else None, flags, stream)
     _lib.check(rc, "bkcore_forward")
     del zkeep
     if _DEBUG["keep_ws"]:
@@ -371,8 +381,8 @@ class FusedBKLayerFunction(torch.autograd.Function):
         apply(v_pre (B,N) f32, h0_diag (N), h0_super, h0_sub (B|1, N-1), z, v_max, feature_clamp|None)
             -> (clamp(features) (B,N,2) f32, G_ii (B,N) complex64)
 
-    Forward: one prologue launch (nan_to_num, tanh saturation, + h0_diag, bfloat16), the operator on bfloat16
-    operands, the clamp in place.  Backward: one launch for the whole chain (reference-mode gradient only; the
+    Forward: one prologue launch (nan_to_num, tanh saturation, + h0_diag, bfloat16), then the operator on bfloat16
+    operands with the clamp folded into its store of the features.  Backward: one launch for the whole chain (reference-mode gradient only; the
     gradient reaches ``v_pre`` alone, as in the reference where the off-diagonals are buffers).  ``GRAD_BLEND`` and
     ``PHI_K_INDEX`` are read from ``BKCoreFunction``."""
 
@@ -390,9 +400,8 @@ class FusedBKLayerFunction(torch.autograd.Function):
             b = b.expand(B, -1)
         if c.shape[0] != B:
             c = c.expand(B, -1)
-        feats, G = bk_forward(he, b, c, z, raw=False, phi_exact=(BKCoreFunction.PHI_K_INDEX == "exact"))
-        if feature_clamp is not None:
-            feats.clamp_(-float(feature_clamp), float(feature_clamp))
+        feats, G = bk_forward(he, b, c, z, raw=False, phi_exact=(BKCoreFunction.PHI_K_INDEX == "exact"),
+                              feature_clamp=feature_clamp)
         ctx.set_materialize_grads(False)
         ctx.bk_v_max = float(v_max)
         ctx.bk_clamp = feature_clamp

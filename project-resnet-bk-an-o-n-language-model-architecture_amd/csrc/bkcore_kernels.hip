@@ -448,6 +448,7 @@ struct RowCfg {
   long N;
   bool raw;     // no clamp / sanitise
   bool fix_bc;  // replace NaN in b/c by 1 (second launch when he_diag held a NaN)
+  float fclamp; // the features output is clamp(Re G, Im G; +-fclamp) (+inf: no clamp); G itself is never clamped
 };
 
 // Stages chunk at `base` of one row into LDS: a_s[idx] = a[base+idx], k_s[idx] = b[g] c[g] with g = base-1+idx
@@ -760,7 +761,9 @@ __device__ __forceinline__ void sweepB_range(const TIn *__restrict__ a, const TI
       if (!TAIL || idx < n_here) {
         const float2 g = SAVE ? sh.u.out_s[pad16(idx)] : fix_tiny(sh.u.out_s[pad16(idx)]);
         Gc[idx] = g;
-        if (Fc) Fc[idx] = g;
+        if (Fc)
+          Fc[idx] = make_float2(__builtin_amdgcn_fmed3f(g.x, -cfg.fclamp, cfg.fclamp),
+                                __builtin_amdgcn_fmed3f(g.y, -cfg.fclamp, cfg.fclamp));
       }
     }
   };
@@ -783,7 +786,7 @@ template <typename TIn, bool PHI_EXACT, bool FAST, bool SAVE>
 __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
     const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
     const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, float2 *__restrict__ G_,
-    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, int second, unsigned flags,
+    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, int second, unsigned flags, float fclamp,
     float2 *__restrict__ save_r_, float2 *__restrict__ save_s_) {
   __shared__ Shared sh;
   const long row = blockIdx.x;
@@ -810,6 +813,7 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
   cfg.N = N;
   cfg.raw = (flags & BKCORE_FLAG_RAW) != 0;
   cfg.fix_bc = fix_bc;
+  cfg.fclamp = fclamp;
 
   const int t = threadIdx.x;
   ScanCtx ctx;
@@ -997,6 +1001,7 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_split_aggregate_kerne
   cfg.N = N;
   cfg.raw = (flags & BKCORE_FLAG_RAW) != 0;
   cfg.fix_bc = false;
+  cfg.fclamp = __builtin_huge_valf();
   const int t = threadIdx.x;
   ScanCtx ctx;
   ctx.nscan = 0;
@@ -1209,7 +1214,8 @@ template <typename TIn, bool PHI_EXACT>
 __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_split_output_kernel(
     const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
     const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, float2 *__restrict__ G_,
-    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, unsigned flags, int S, int seg_ch) {
+    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, unsigned flags, float fclamp, int S,
+    int seg_ch) {
   __shared__ Shared sh;
   const long row = blockIdx.x / S;
   const int sg = blockIdx.x % S;
@@ -1231,6 +1237,7 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_split_output_kernel(
   cfg.N = N;
   cfg.raw = (flags & BKCORE_FLAG_RAW) != 0;
   cfg.fix_bc = false;
+  cfg.fclamp = fclamp;
   const int t = threadIdx.x;
   ScanCtx ctx;
   ctx.nscan = 0;
@@ -1493,8 +1500,8 @@ template <typename TIn, bool PHI_EXACT, int MODE, bool SAVE = false>
 __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
     const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
     const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, float2 *__restrict__ G_,
-    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, unsigned flags, int S, int seg_ch,
-    float2 *__restrict__ save_r_ = nullptr, float2 *__restrict__ save_s_ = nullptr) {
+    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, unsigned flags, float fclamp, int S,
+    int seg_ch, float2 *__restrict__ save_r_ = nullptr, float2 *__restrict__ save_s_ = nullptr) {
   __shared__ SharedR sh;
   const long row = MODE == 0 ? (long)blockIdx.x : (long)(blockIdx.x / S);
   const int sg = MODE == 0 ? 0 : (int)(blockIdx.x % S);
@@ -1514,6 +1521,7 @@ __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
   cfg.N = N;
   cfg.raw = (flags & BKCORE_FLAG_RAW) != 0;
   cfg.fix_bc = false;
+  cfg.fclamp = fclamp;
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
@@ -1710,8 +1718,8 @@ __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
         __builtin_nontemporal_store(gv.x, &Gc[idx].x);
         __builtin_nontemporal_store(gv.y, &Gc[idx].y);
         if (Fc) {
-          __builtin_nontemporal_store(gv.x, &Fc[idx].x);
-          __builtin_nontemporal_store(gv.y, &Fc[idx].y);
+          __builtin_nontemporal_store(__builtin_amdgcn_fmed3f(gv.x, -cfg.fclamp, cfg.fclamp), &Fc[idx].x);
+          __builtin_nontemporal_store(__builtin_amdgcn_fmed3f(gv.y, -cfg.fclamp, cfg.fclamp), &Fc[idx].y);
         }
       }
     }
@@ -1963,7 +1971,8 @@ inline void split_plan(int64_t B, int64_t N, int &S, int &seg_ch) {
 template <typename TIn, bool PHI_EXACT, bool SAVE>
 int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
                     const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
-                    void *ws, void *state, unsigned flags, hipStream_t stream, float *save_r, float *save_s) {
+                    void *ws, void *state, unsigned flags, hipStream_t stream, float *save_r, float *save_s,
+                    float fclamp = __builtin_huge_valf()) {
   int call_id = 0;
   if (state) {
     call_id = __atomic_add_fetch(&g_call_counter, 1, __ATOMIC_RELAXED);
@@ -1976,7 +1985,7 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
   hipLaunchKernelGGL((bk_forward_kernel<TIn, PHI_EXACT, FASTV, SAVE>), dim3((unsigned)B), dim3(T), 0, stream,        \
                      (const TIn *)a, (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re,   \
                      z_im, (long)B, (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id,     \
-                     SECOND, flags, (float2 *)save_r, (float2 *)save_s)
+                     SECOND, flags, fclamp, (float2 *)save_r, (float2 *)save_s)
   int S = 1, seg_ch = 0;
   if (state && !SAVE) split_plan(B, N, S, seg_ch);
   if (S > 1 && !(flags & BKCORE_FLAG_SCAN_PATH)) {
@@ -1986,7 +1995,8 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
 #define BK_RATIO_SEG(MODE)                                                                                           \
   hipLaunchKernelGGL((bk_ratio_forward_kernel<TIn, PHI_EXACT, MODE>), dim3(grid), dim3(T), 0, stream, (const TIn *)a, \
                      (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re, z_im, (long)B,     \
-                     (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id, flags, S, seg_ch)
+                     (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id, flags, fclamp, S,   \
+                     seg_ch)
     BK_RATIO_SEG(1);
     hipLaunchKernelGGL(bk_ratio_combine_kernel, dim3((unsigned)B), dim3(64), 0, stream, (long)B, (long)N, (char *)ws,
                        (int *)state, call_id, S);
@@ -2011,7 +2021,8 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
                        (char *)ws, (int *)state, call_id, S);
     hipLaunchKernelGGL((bk_split_output_kernel<TIn, PHI_EXACT>), dim3(grid), dim3(T), 0, stream, (const TIn *)a,
                        (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re, z_im, (long)B,
-                       (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id, flags, S, seg_ch);
+                       (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id, flags, fclamp, S,
+                       seg_ch);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) {
       BK_LAUNCH(false, 1);
@@ -2026,7 +2037,7 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
     hipLaunchKernelGGL((bk_ratio_forward_kernel<TIn, PHI_EXACT, 0, SAVE>), dim3((unsigned)B), dim3(T), 0, stream,
                        (const TIn *)a, (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re,
                        z_im, (long)B, (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id,
-                       flags, 1, 0, (float2 *)save_r, (float2 *)save_s);
+                       flags, fclamp, 1, 0, (float2 *)save_r, (float2 *)save_s);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) {
       BK_LAUNCH(false, 1);
@@ -2064,12 +2075,12 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
 template <typename TIn>
 int launch_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
                    const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
-                   void *ws, void *state, unsigned flags, hipStream_t s) {
+                   void *ws, void *state, unsigned flags, hipStream_t s, float fclamp) {
   if (flags & BKCORE_FLAG_PHI_EXACT)
     return launch_forward2<TIn, true, false>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
-                                             flags, s, nullptr, nullptr);
+                                             flags, s, nullptr, nullptr, fclamp);
   return launch_forward2<TIn, false, false>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
-                                            flags, s, nullptr, nullptr);
+                                            flags, s, nullptr, nullptr, fclamp);
 }
 
 }  // namespace
@@ -2084,9 +2095,12 @@ size_t bkcore_workspace_bytes(int64_t B, int64_t N) {
   return rowflag_bytes(B) + lane_state_bytes(B, N) + seg_records;
 }
 
-int bkcore_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc, int in_dtype,
-                   const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
-                   void *workspace, size_t workspace_bytes, void *state, unsigned flags, void *stream) {
+int bkcore_forward_clamped(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
+                           int in_dtype, const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G,
+                           float *features, float feature_clamp, void *workspace, size_t workspace_bytes, void *state,
+                           unsigned flags, void *stream) {
+  const float fclamp = feature_clamp > 0.0f ? feature_clamp : __builtin_huge_valf();
+  if (feature_clamp != feature_clamp) return BKCORE_EINVAL;
   if (B < 0 || N < 0 || lda < 0 || ldb < 0 || ldc < 0) return BKCORE_EINVAL;
   if (B == 0 || N == 0) return BKCORE_OK;
   if (!a || !G || (N > 1 && (!b || !c))) return BKCORE_EINVAL;
@@ -2097,18 +2111,29 @@ int bkcore_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const
   hipStream_t s = (hipStream_t)stream;
   switch (in_dtype) {
     case BKCORE_F32:
-      return launch_forward<float>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, workspace, state, flags, s);
+      return launch_forward<float>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, workspace, state, flags, s,
+                                   fclamp);
 #ifndef BK_DEV_F32_ONLY
     case BKCORE_BF16:
-      return launch_forward<uint16_t>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, workspace, state, flags, s);
+      return launch_forward<uint16_t>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, workspace, state, flags, s,
+                                   fclamp);
     case BKCORE_F16:
-      return launch_forward<_Float16>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, workspace, state, flags, s);
+      return launch_forward<_Float16>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, workspace, state, flags, s,
+                                   fclamp);
     case BKCORE_F64:
-      return launch_forward<double>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, workspace, state, flags, s);
+      return launch_forward<double>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, workspace, state, flags, s,
+                                   fclamp);
 #endif
     default:
       return BKCORE_EINVAL;
   }
+}
+
+int bkcore_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc, int in_dtype,
+                   const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
+                   void *workspace, size_t workspace_bytes, void *state, unsigned flags, void *stream) {
+  return bkcore_forward_clamped(a, lda, b, ldb, c, ldc, in_dtype, z_dev, z_re, z_im, B, N, G, features, 0.0f, workspace,
+                                workspace_bytes, state, flags, stream);
 }
 
 int bkcore_internal_forward_save(const float *a, int64_t lda, const float *b, int64_t ldb, const float *c, int64_t ldc,
@@ -2207,7 +2232,7 @@ int bkcore_layer_backward_ref(const float *G, const float *grad_features, const 
 
 int64_t bkcore_max_seq_len(void) { return (int64_t)MAX_N; }
 int bkcore_last_hip_error(void) { return g_last_hip_error; }
-int bkcore_abi_version(void) { return 5; }
+int bkcore_abi_version(void) { return 6; }
 
 const char *bkcore_error_string(int code) {
   switch (code) {

@@ -145,3 +145,35 @@ def test_layer_fused_option_matches_unfused_layer():
             continue
         torch.testing.assert_close(p2.grad, p1.grad, rtol=2e-2, atol=1e-3 * float(p1.grad.abs().max()) + 1e-9, msg=n1)
     assert lb.last_g_ii.shape == (B, N, 1) and lb.last_g_ii.dtype == torch.complex64
+
+
+@pytest.mark.parametrize("B,N,kind", [(6, 300, "good"), (3, 9000, "good"), (4, 40000, "good"), (4, 40000, "scan"),
+                                      (5, 5000, "illcond"), (2, 1, "good")])
+def test_forward_clamped_features(B, N, kind):
+    """bkcore_forward_clamped: features = clamp(features of bkcore_forward), G untouched, on every forward path (one
+    workgroup per row, several per row, scan first launch, rows recomputed by the second launch)."""
+    _need_gpu()
+    import bkcore
+    from bkcore import bk_core
+    g = torch.Generator(device="cuda").manual_seed(N + B)
+    if kind == "illcond":
+        a = torch.randn(B, N, generator=g, device="cuda")
+        b = torch.randn(B, max(N - 1, 0), generator=g, device="cuda")
+        c = torch.randn(B, max(N - 1, 0), generator=g, device="cuda")
+        z = 0.1 + 0.1j
+    else:
+        a = -2.0 + 0.5 * torch.randn(B, N, generator=g, device="cuda")
+        b = torch.ones(B, max(N - 1, 0), device="cuda")
+        c = b
+        z = 1j
+    bk_core._DEBUG["scan_path"] = kind == "scan"
+    try:
+        f0, G0 = bkcore.bk_forward(a, b, c, z)
+        f1, G1 = bkcore.bk_forward(a, b, c, z, feature_clamp=0.25)
+    finally:
+        bk_core._DEBUG["scan_path"] = False
+    assert torch.equal(G0, G1)
+    assert torch.equal(f1, torch.clamp(f0, -0.25, 0.25))
+    assert float(f0.abs().max()) > 0.25                      # the clamp was active somewhere
+    with pytest.raises(ValueError):
+        bkcore.bk_forward(a, b, c, z, feature_clamp=0.0)
