@@ -156,6 +156,30 @@ int bkcore_layer_backward_ref(const float *G, const float *grad_features, const 
                               float feature_clamp, const float *v_pre, float v_max, int round_bf16, int64_t n,
                               float *grad_v, void *stream);
 
+/*
+ * The spectral branch's output stage: out = residual + bk_scale * (features @ weight^T + bias), replacing
+ * `spec_out = self.output_proj(features); output = ffn_out + self.bk_scale * spec_out`
+ * (src/models/resnet_bk.py:218-219; output_proj = nn.Linear(2, D), :86-87) in one pass.
+ *
+ * features: n*2 floats (already clamped); weight: D*2 floats (row d = weights of output d, the layout of
+ * nn.Linear(2, D).weight); bias, scale: D floats; residual: n*D floats or NULL; out: n*D floats.  n = B*N positions.
+ */
+int bkcore_layer_epilogue(const float *features, const float *weight, const float *bias, const float *scale,
+                          const float *residual, int64_t n, int64_t D, float *out, void *stream);
+
+/*
+ * Backward of bkcore_layer_epilogue in one pass over grad_out (n*D floats): grad_features (n*2 floats), and -- each
+ * optional -- grad_weight (D*2), grad_bias (D), grad_scale (D).  The gradient of `residual` is grad_out itself.
+ * Replaces the autograd chain of src/models/resnet_bk.py:218-219.  Column sums are formed per workgroup and combined
+ * in a fixed order (deterministic).  D <= 1024 (BKCORE_EINVAL beyond).  workspace: at least
+ * bkcore_layer_epilogue_backward_workspace_bytes(n, D) bytes.
+ */
+int bkcore_layer_epilogue_backward(const float *grad_out, const float *features, const float *weight, const float *bias,
+                                   const float *scale, int64_t n, int64_t D, float *grad_features, float *grad_weight,
+                                   float *grad_bias, float *grad_scale, void *workspace, size_t workspace_bytes,
+                                   void *stream);
+size_t bkcore_layer_epilogue_backward_workspace_bytes(int64_t n, int64_t D);
+
 /* Largest N bkcore_forward accepts. */
 int64_t bkcore_max_seq_len(void);
 /* HIP error code of the last failed launch on this thread (0 if none). */

@@ -1,10 +1,10 @@
 """MI355X-native BK-Core: host-side mirror of the reference operator API (src/models/bk_core.py)."""
 from .bk_core import (BKCoreFunction, get_tridiagonal_inverse_diagonal, vmapped_get_diag, set_triton_mode,
                       get_triton_mode, bk_forward, bk_backward_reference, bk_backward_analytic,
-                      sanitise_inputs, FusedBKLayerFunction, layer_prologue, layer_backward_reference)
+                      sanitise_inputs, FusedBKLayerFunction, FusedSpectralOutputFunction, layer_prologue, layer_backward_reference)
 
 from .layers import BKCoreLayer, CUDAOptimizedBKCore, LearnedTridiagonalGreen
 
 __all__ = ["BKCoreLayer", "CUDAOptimizedBKCore", "LearnedTridiagonalGreen", "BKCoreFunction", "get_tridiagonal_inverse_diagonal", "vmapped_get_diag", "set_triton_mode",
-           "get_triton_mode", "bk_forward", "bk_backward_reference", "bk_backward_analytic", "sanitise_inputs", "FusedBKLayerFunction",
+           "get_triton_mode", "bk_forward", "bk_backward_reference", "bk_backward_analytic", "sanitise_inputs", "FusedBKLayerFunction", "FusedSpectralOutputFunction",
            "layer_prologue", "layer_backward_reference"]

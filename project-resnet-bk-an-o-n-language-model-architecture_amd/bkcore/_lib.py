@@ -19,6 +19,7 @@ EINVAL, ETOOLONG, ELAUNCH, EWORKSPACE = -1, -2, -3, -4
 
 EXPORTS = ("bkcore_forward", "bkcore_forward_clamped", "bkcore_workspace_bytes", "bkcore_backward_ref", "bkcore_backward_analytic",
            "bkcore_backward_analytic_workspace_bytes", "bkcore_layer_prologue", "bkcore_layer_backward_ref",
+           "bkcore_layer_epilogue", "bkcore_layer_epilogue_backward", "bkcore_layer_epilogue_backward_workspace_bytes",
            "bkcore_max_seq_len", "bkcore_last_hip_error",
            "bkcore_error_string", "bkcore_abi_version")
 
@@ -54,6 +55,12 @@ def load():
     L.bkcore_layer_prologue.restype = i32
     L.bkcore_layer_backward_ref.argtypes = [vp, vp, vp, f32, f32, vp, f32, i32, i64, vp, vp]
     L.bkcore_layer_backward_ref.restype = i32
+    L.bkcore_layer_epilogue.argtypes = [vp, vp, vp, vp, vp, i64, i64, vp, vp]
+    L.bkcore_layer_epilogue.restype = i32
+    L.bkcore_layer_epilogue_backward.argtypes = [vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.bkcore_layer_epilogue_backward.restype = i32
+    L.bkcore_layer_epilogue_backward_workspace_bytes.argtypes = [i64, i64]
+    L.bkcore_layer_epilogue_backward_workspace_bytes.restype = ctypes.c_size_t
     L.bkcore_max_seq_len.restype = i64
     L.bkcore_last_hip_error.restype = i32
     L.bkcore_error_string.argtypes = [i32]

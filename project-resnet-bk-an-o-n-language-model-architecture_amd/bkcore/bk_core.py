@@ -418,6 +418,71 @@ class FusedBKLayerFunction(torch.autograd.Function):
         return grad_v, None, None, None, None, None, None
 
 
+class FusedSpectralOutputFunction(torch.autograd.Function):
+    """out = residual + bk_scale * output_proj(features) of the reference layer (src/models/resnet_bk.py:218-219) in
+    one launch forward and one pass over the incoming gradient backward.
+
+        apply(features (..., 2) f32, weight (D, 2), bias (D,), bk_scale (D,), residual (..., D) f32 | None) -> (..., D) f32
+    """
+
+    @staticmethod
+    def forward(ctx, features, weight, bias, scale, residual):
+        L = _lib.load()
+        if not features.is_cuda:
+            raise RuntimeError("bkcore: tensors must be on a ROCm device (no CPU path)")
+        D = weight.shape[0]
+        if weight.shape != (D, 2) or bias.shape != (D,) or scale.shape != (D,) or features.shape[-1] != 2:
+            raise ValueError("bkcore: expected features (..., 2), weight (D, 2), bias (D,), bk_scale (D,)")
+        if D > 1024:
+            raise ValueError("bkcore: FusedSpectralOutputFunction supports D <= 1024")
+        lead = features.shape[:-1]
+        f = features.detach().float().contiguous()
+        w, bb, sc = (t.detach().float().contiguous() for t in (weight, bias, scale))
+        n = f.numel() // 2
+        res = None
+        if residual is not None:
+            if residual.shape != (*lead, D):
+                raise ValueError(f"bkcore: residual must have shape {(*lead, D)}, got {tuple(residual.shape)}")
+            res = residual.detach().float().contiguous()
+        out = torch.empty((*lead, D), dtype=torch.float32, device=f.device)
+        if n and D:
+            with torch.cuda.device(f.device):
+                rc = L.bkcore_layer_epilogue(f.data_ptr(), w.data_ptr(), bb.data_ptr(), sc.data_ptr(),
+                                             res.data_ptr() if res is not None else None, n, D, out.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "bkcore_layer_epilogue")
+        ctx.save_for_backward(f, w, bb, sc)
+        ctx.bk_has_res = residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        L = _lib.load()
+        f, w, bb, sc = ctx.saved_tensors
+        D = w.shape[0]
+        n = f.numel() // 2
+        go = grad_out.float().contiguous()
+        gf = torch.empty_like(f)
+        need_w, need_b, need_s = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        gw = torch.empty_like(w) if need_w else None
+        gb = torch.empty_like(bb) if need_b else None
+        gs = torch.empty_like(sc) if need_s else None
+        if n and D:
+            with torch.cuda.device(f.device):
+                nbytes = int(L.bkcore_layer_epilogue_backward_workspace_bytes(n, D))
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=f.device)
+                ptr = lambda t: t.data_ptr() if t is not None else None
+                rc = L.bkcore_layer_epilogue_backward(go.data_ptr(), f.data_ptr(), w.data_ptr(), bb.data_ptr(),
+                                                      sc.data_ptr(), n, D, gf.data_ptr(), ptr(gw), ptr(gb), ptr(gs),
+                                                      ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "bkcore_layer_epilogue_backward")
+        else:
+            for t in (gf, gw, gb, gs):
+                if t is not None:
+                    t.zero_()
+        return (gf if ctx.needs_input_grad[0] else None, gw, gb, gs, go if ctx.bk_has_res else None)
+
+
 def set_triton_mode(enabled: bool):
     """Kept for source compatibility (reference bk_core.py:389-416).  There is no Triton back-end here;
     the flag is recorded and selects nothing."""

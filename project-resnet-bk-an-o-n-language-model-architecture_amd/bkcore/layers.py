@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .bk_core import BKCoreFunction, FusedBKLayerFunction
+from .bk_core import BKCoreFunction, FusedBKLayerFunction, FusedSpectralOutputFunction
 
 
 class BKCoreLayer(nn.Module):
@@ -85,12 +85,18 @@ class BKCoreLayer(nn.Module):
     def _use_fused(self) -> bool:
         return (self.fused and self.bk_core == BKCoreFunction.apply and BKCoreFunction.GRAD_MODE == "reference")
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """The layer's spectral branch: bk_scale * output_proj(clamp(features)) (resnet_bk.py:216-219)."""
+    def forward(self, x: torch.Tensor, residual: torch.Tensor | None = None) -> torch.Tensor:
+        """The layer's spectral branch: [residual +] bk_scale * output_proj(clamp(features)) (resnet_bk.py:216-219;
+        ``residual`` is the reference's ``ffn_out``)."""
         features, _ = self.spectral_features(x)
-        if self.feature_clamp is not None and not self._use_fused():   # the fused path returns clamped features
+        if self._use_fused():                                          # clamped features; one launch for the rest
+            if features.dtype == torch.float32 and self.d_model <= 1024:
+                return FusedSpectralOutputFunction.apply(features, self.output_proj.weight, self.output_proj.bias,
+                                                         self.bk_scale, residual)
+        elif self.feature_clamp is not None:
             features = torch.clamp(features, -self.feature_clamp, self.feature_clamp)
-        return self.bk_scale * self.output_proj(features)
+        out = self.bk_scale * self.output_proj(features)
+        return out if residual is None else residual + out
 
 
 class CUDAOptimizedBKCore(nn.Module):

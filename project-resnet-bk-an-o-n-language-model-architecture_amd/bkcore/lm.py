@@ -25,6 +25,8 @@ class ResNetBKBlock(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         h = self.layer_norm(x)
+        if self.bk_layer.fused:          # ffn_out + bk_scale * spec_out in the layer's output launch (resnet_bk.py:219)
+            return x + self.bk_layer(h, residual=self.ffn(h))
         return x + self.bk_layer(h) + self.ffn(h)
 
 

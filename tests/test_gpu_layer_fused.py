@@ -177,3 +177,55 @@ def test_forward_clamped_features(B, N, kind):
     assert float(f0.abs().max()) > 0.25                      # the clamp was active somewhere
     with pytest.raises(ValueError):
         bkcore.bk_forward(a, b, c, z, feature_clamp=0.0)
+
+
+@pytest.mark.parametrize("lead,D,with_res", [((3, 50), 256, True), ((1, 1), 4, False), ((7, 33), 30, True),
+                                             ((2, 200), 1024, False), ((1500,), 64, True)])
+def test_spectral_output_matches_tensor_ops(lead, D, with_res):
+    """bkcore_layer_epilogue / _backward against residual + bk_scale * Linear(2 -> D)(features) under autograd."""
+    _need_gpu()
+    import bkcore
+    g = torch.Generator(device="cuda").manual_seed(D)
+    mk = lambda *s: torch.randn(*s, generator=g, device="cuda")
+    f0, W0, b0, s0 = mk(*lead, 2), mk(D, 2), mk(D), 1.0 + 0.1 * mk(D)
+    r0 = mk(*lead, D) if with_res else None
+    go = mk(*lead, D)
+
+    def run(fn):
+        leaves = [t.clone().requires_grad_(True) for t in (f0, W0, b0, s0)]
+        res = r0.clone().requires_grad_(True) if with_res else None
+        out = fn(*leaves, res)
+        out.backward(go)
+        return out.detach(), [t.grad for t in leaves] + ([res.grad] if with_res else [])
+
+    def plain(f, W, b, s, res):
+        y = s * torch.nn.functional.linear(f, W, b)
+        return y if res is None else res + y
+
+    out_a, grads_a = run(plain)
+    out_b, grads_b = run(bkcore.FusedSpectralOutputFunction.apply)
+    torch.testing.assert_close(out_b, out_a, rtol=1e-5, atol=1e-5)
+    n = f0.numel() // 2
+    for ga, gb, name in zip(grads_a, grads_b, ("features", "weight", "bias", "bk_scale", "residual")):
+        assert gb.shape == ga.shape, name
+        # sums of n (columns) or D (features) float32 products in a different order
+        atol = 2e-6 * float(ga.abs().max()) * max(n, D) ** 0.5 + 1e-6
+        torch.testing.assert_close(gb, ga, rtol=1e-4, atol=atol, msg=lambda m, name=name: f"{name}: {m}")
+    # deterministic: the same call twice gives the same bits
+    _, grads_c = run(bkcore.FusedSpectralOutputFunction.apply)
+    assert all(torch.equal(x, y) for x, y in zip(grads_b, grads_c))
+
+
+def test_spectral_output_limits():
+    _need_gpu()
+    import bkcore
+    f = torch.randn(4, 2, device="cuda", requires_grad=True)
+    W = torch.randn(2048, 2, device="cuda")
+    with pytest.raises(ValueError, match="1024"):
+        bkcore.FusedSpectralOutputFunction.apply(f, W, torch.zeros(2048, device="cuda"),
+                                                 torch.ones(2048, device="cuda"), None)
+    with pytest.raises(ValueError):
+        bkcore.FusedSpectralOutputFunction.apply(f, W[:8, :1], torch.zeros(8, device="cuda"),
+                                                 torch.ones(8, device="cuda"), None)
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        bkcore.FusedSpectralOutputFunction.apply(torch.zeros(4, 2), torch.zeros(8, 2), torch.zeros(8), torch.ones(8), None)

@@ -46,3 +46,38 @@ def timed(fn, reps=20):
 
 tu, tf = timed(unfused), timed(fused)
 print(json.dumps({"B": B, "N": N, "unfused_fwd_bwd_ms": tu, "fused_fwd_bwd_ms": tf, "speedup": tu / tf}))
+
+# output stage: residual + bk_scale * Linear(2 -> D)(features), forward + backward, n positions
+for n_pos, D in ((8 * 256, 256), (64 * 2048, 256), (1024 * 1024, 256)):
+    f0 = torch.randn(n_pos, 2, generator=g, device=dev)
+    lin = torch.nn.Linear(2, D).to(dev)
+    sc = torch.ones(D, device=dev, requires_grad=True)
+    r0 = torch.randn(n_pos, D, generator=g, device=dev)
+    go = torch.randn(n_pos, D, generator=g, device=dev)
+
+    def plain(f, r):
+        return r + sc * lin(f)
+
+    def fused_out(f, r):
+        return bkcore.FusedSpectralOutputFunction.apply(f, lin.weight, lin.bias, sc, r)
+
+    def timed2(fn, reps=20):
+        def step():
+            f = f0.detach().requires_grad_(True)
+            r = r0.detach().requires_grad_(True)
+            lin.zero_grad(set_to_none=True); sc.grad = None
+            fn(f, r).backward(go)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    tu, tf = timed2(plain), timed2(fused_out)
+    print(json.dumps({"output_stage_positions": n_pos, "D": D, "unfused_fwd_bwd_ms": tu, "fused_fwd_bwd_ms": tf,
+                      "speedup": tu / tf}))
