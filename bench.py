@@ -203,6 +203,25 @@ def main():
                 G3 = bkcore.bk_forward(a3, b3, c3, z3)[1]
                 t3f = timed(lambda: bkcore.bk_forward(a3, b3, c3, z3), reps)
                 t3b = timed(lambda: bkcore.bk_backward_reference(G3, g3, None, 0.5), reps)
+            # per-iteration stream events over 100 iterations after 10 warm-ups: median and minimum of forward+backward
+            # and of the forward alone (the protocol of the reference's own benchmark, scripts/benchmark_bk_triton.py:101-119)
+            def per_iter(fn, iters=100, warm=10):
+                for _ in range(warm):
+                    fn()
+                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+                for e0, e1 in ev:
+                    e0.record()
+                    fn()
+                    e1.record()
+                torch.cuda.synchronize()
+                ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+                return ts[len(ts) // 2], ts[0]
+            with torch.no_grad():
+                fb_med, fb_min = per_iter(lambda: bkcore.bk_backward_reference(
+                    bkcore.bk_forward(ad, b, c, z)[1], gfeat, None, 0.5))
+                f_med, f_min = per_iter(lambda: bkcore.bk_forward(ad, b, c, z))
+            out["events_100_iters"] = {"fwd_bwd_ms_median": fb_med, "fwd_bwd_ms_min": fb_min,
+                                       "fwd_ms_median": f_med, "fwd_ms_min": f_min}
             out["secondary"] = {
                 "analytic_backward_ms": t_ana * 1e3,
                 "analytic_backward_note": "grad for he_diag, h0_super, h0_sub; re-runs the forward inside",
