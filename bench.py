@@ -180,7 +180,8 @@ def main():
                        "rows_per_gpu": B, "seq_len": N, "sharding": f"batch rows x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": fwd_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": fwd_bw / HBM_PEAK, "traffic": traffic,
-                         "kernel": "bk_ratio_forward_kernel", "bytes_per_elem": FWD_BYTES, "launch_ms": t_fwd * 1e3},
+                         "kernel": "bk_ratio_forward_kernel", "bytes_per_elem": FWD_BYTES, "launch_ms": t_fwd * 1e3,
+                         "launch_ms_covers": "one forward call = this kernel + the (empty) second launch, ~5 us"},
             "fwd_ms": t_fwd * 1e3,
             "bwd_ms": t_bwd * 1e3,
             "bwd_GBps": BWD_BYTES * elems / t_bwd / 1e9,
