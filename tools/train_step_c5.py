@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--fused", action="store_true", help="elementwise steps around the operator inside the library")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole step (forward, backward, clip, AdamW) in one HIP graph and replay it (1 GPU)")
     args = ap.parse_args()
     rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -33,19 +35,36 @@ def main():
     model = SmallResNetBKLM(fused=args.fused).to(device)
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index])
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01, capturable=bool(args.graph))
     g = torch.Generator(device=device).manual_seed(100 + rank)
     n_seq = 256
     tokens = torch.randint(0, 50257, (args.batch, n_seq), device=device, generator=g)
     targets = torch.randint(0, 50257, (args.batch, n_seq), device=device, generator=g)
+    step = lambda: training_step(model, opt, tokens, targets)
+    if args.graph:
+        assert world == 1, "--graph is a single-GPU mode"
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up outside the capture (allocator, lazy init)
+            for _ in range(3):
+                training_step(model, opt, tokens, targets)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            static_loss = training_step(model, opt, tokens, targets)
+
+        def step():
+            graph.replay()
+            return static_loss
     for _ in range(args.warmup):
-        loss = training_step(model, opt, tokens, targets)
+        loss = step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = training_step(model, opt, tokens, targets)
+        loss = step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -57,7 +76,7 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "resnet_bk_small_lm_train_tokens_per_sec", "value": world * args.batch * n_seq * args.steps / dt,
                           "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
-                          "final_loss": float(loss), "fused_layer": bool(args.fused), "config": {"workload": "phase7_small dims: d_model 256, 4 layers, n_seq 256, "
+                          "final_loss": float(loss), "fused_layer": bool(args.fused), "hip_graph": bool(args.graph), "config": {"workload": "phase7_small dims: d_model 256, 4 layers, n_seq 256, "
                           f"batch {args.batch}/GPU, vocab 50257, AdamW 1e-4, clip 1.0; dummy tokens", "parallelism": f"dp{world}"}}))
     if world > 1:
         dist.destroy_process_group()
