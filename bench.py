@@ -85,8 +85,8 @@ def cpu_baseline_torch_loop(N_sub=16384, B=64):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024, help="rows per GPU")
     ap.add_argument("--seq", type=int, default=32768)
     ap.add_argument("--no-cpu-baseline", action="store_true")
