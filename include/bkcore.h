@@ -180,6 +180,15 @@ int bkcore_layer_epilogue_backward(const float *grad_out, const float *features,
                                    void *stream);
 size_t bkcore_layer_epilogue_backward_workspace_bytes(int64_t n, int64_t D);
 
+/*
+ * Cumulative sum along the middle dimension of a contiguous float32 tensor viewed as (outer, L, inner):
+ * y[o, l, i] = sum_{l' <= l} x[o, l', i]  (reverse != 0: sum over l' >= l).  Replaces
+ * fused_associative_scan(x, dim, reverse), src/kernels/associative_scan.py:211-308, and the torch.cumsum it falls back
+ * to in the AR-SSM layer (src/models/phase1/ar_ssm_layer.py:517-525: k_cumsum over dim 1 of (B, L, rank)).
+ * x, y: outer*L*inner floats, distinct buffers.
+ */
+int bkcore_cumsum(const float *x, float *y, int64_t outer, int64_t L, int64_t inner, int reverse, void *stream);
+
 /* Largest N bkcore_forward accepts. */
 int64_t bkcore_max_seq_len(void);
 /* HIP error code of the last failed launch on this thread (0 if none). */
