@@ -189,6 +189,20 @@ size_t bkcore_layer_epilogue_backward_workspace_bytes(int64_t n, int64_t D);
  */
 int bkcore_cumsum(const float *x, float *y, int64_t outer, int64_t L, int64_t inner, int reverse, void *stream);
 
+/*
+ * Woodbury low-rank correction of the resolvent diagonal for every row of a batch:
+ *     out_b = G_b - G_b^2 * rowsum((U (I + V^T diag(G_b) U)^{-1}) o V)
+ * Replaces the Python loop over the batch in BirmanSchwingerCore.compute_semiseparable_resolvent,
+ * src/models/birman_schwinger_core.py:567-604 (complex64 arithmetic as there, :563).
+ *
+ * G, out: B*N complex64; U, V: N*r floats, row-major (N, r) as SemiseparableMatrix.U / .V; r <= 22; B <= 65535.
+ * A row whose r x r system is singular to working precision is returned uncorrected (the reference falls back to a
+ * pseudo-inverse there, :584-586).  workspace: at least bkcore_woodbury_workspace_bytes(B, N, r) bytes.
+ */
+int bkcore_woodbury_correct(const float *G, const float *U, const float *V, int64_t B, int64_t N, int64_t r,
+                            float *out, void *workspace, size_t workspace_bytes, void *stream);
+size_t bkcore_woodbury_workspace_bytes(int64_t B, int64_t N, int64_t r);
+
 /* Largest N bkcore_forward accepts. */
 int64_t bkcore_max_seq_len(void);
 /* HIP error code of the last failed launch on this thread (0 if none). */

@@ -14,12 +14,12 @@ FLAG_RAW = 1
 FLAG_PHI_EXACT = 2
 FLAG_SCAN_PATH = 4
 STATE_BYTES = 64
-ABI_VERSION = 7
+ABI_VERSION = 8
 EINVAL, ETOOLONG, ELAUNCH, EWORKSPACE = -1, -2, -3, -4
 
 EXPORTS = ("bkcore_forward", "bkcore_forward_clamped", "bkcore_workspace_bytes", "bkcore_backward_ref", "bkcore_backward_analytic",
            "bkcore_backward_analytic_workspace_bytes", "bkcore_layer_prologue", "bkcore_layer_backward_ref",
-           "bkcore_layer_epilogue", "bkcore_layer_epilogue_backward", "bkcore_layer_epilogue_backward_workspace_bytes", "bkcore_cumsum",
+           "bkcore_layer_epilogue", "bkcore_layer_epilogue_backward", "bkcore_layer_epilogue_backward_workspace_bytes", "bkcore_cumsum", "bkcore_woodbury_correct", "bkcore_woodbury_workspace_bytes",
            "bkcore_max_seq_len", "bkcore_last_hip_error",
            "bkcore_error_string", "bkcore_abi_version")
 
@@ -63,6 +63,10 @@ def load():
     L.bkcore_layer_epilogue_backward_workspace_bytes.restype = ctypes.c_size_t
     L.bkcore_cumsum.argtypes = [vp, vp, i64, i64, i64, i32, vp]
     L.bkcore_cumsum.restype = i32
+    L.bkcore_woodbury_correct.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, ctypes.c_size_t, vp]
+    L.bkcore_woodbury_correct.restype = i32
+    L.bkcore_woodbury_workspace_bytes.argtypes = [i64, i64, i64]
+    L.bkcore_woodbury_workspace_bytes.restype = ctypes.c_size_t
     L.bkcore_max_seq_len.restype = i64
     L.bkcore_last_hip_error.restype = i32
     L.bkcore_error_string.argtypes = [i32]

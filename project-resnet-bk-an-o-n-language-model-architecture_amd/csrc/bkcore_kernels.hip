@@ -2232,7 +2232,7 @@ int bkcore_layer_backward_ref(const float *G, const float *grad_features, const 
 
 int64_t bkcore_max_seq_len(void) { return (int64_t)MAX_N; }
 int bkcore_last_hip_error(void) { return g_last_hip_error; }
-int bkcore_abi_version(void) { return 7; }
+int bkcore_abi_version(void) { return 8; }
 
 const char *bkcore_error_string(int code) {
   switch (code) {

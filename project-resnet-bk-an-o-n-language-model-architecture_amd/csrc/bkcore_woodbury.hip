@@ -1,0 +1,210 @@
+// Woodbury low-rank correction of the resolvent diagonal, batched over rows: the loop over the batch of the reference's
+// Birman-Schwinger core (src/models/birman_schwinger_core.py:567-604) as three launches,
+//     M_b   = I + V^T diag(G_b) U                     (r x r complex; bk_woodbury_gram_kernel, O(N r^2) per row)
+//     W_b   = M_b^{-1}                                (bk_woodbury_solve_kernel, Gauss-Jordan with partial pivoting)
+//     out_b = G_b - G_b^2 * rowsum((U W_b) o V)       (bk_woodbury_apply_kernel, O(N r^2) per row)
+// in complex64 like the reference (its tridiagonal diagonal is complex64, :563).  r <= 22 (r = ceil(log2 N) in the
+// reference: every N the operator accepts).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bkcore.h"
+
+namespace {
+
+constexpr int WT = 256;       // threads per workgroup
+constexpr int MAX_R = 22;     // r^2 <= 2 * WT
+constexpr int TN = 64;        // positions staged per pass of the gram kernel
+constexpr int GRAM_SPAN = 2048;  // positions per gram workgroup
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
+  return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+
+// partial[b][s][k*r + l] = sum over the positions n of span s of V[n][k] U[n][l] G[b][n]
+__global__ __launch_bounds__(WT) void bk_woodbury_gram_kernel(const float2 *__restrict__ G,
+                                                              const float *__restrict__ U,
+                                                              const float *__restrict__ V, long N, int r, int spans,
+                                                              float2 *__restrict__ partial) {
+  __shared__ float Us[TN][MAX_R + 1], Vs[TN][MAX_R + 1];
+  __shared__ float2 Gs[TN];
+  const long b = blockIdx.x / spans;
+  const int sp = blockIdx.x % spans;
+  const long n0 = (long)sp * GRAM_SPAN, n1 = min(N, n0 + GRAM_SPAN);
+  const int t = threadIdx.x, rr = r * r;
+  const int p0 = t, p1 = t + WT;
+  const int k0 = p0 / r, l0 = p0 % r, k1 = p1 / r, l1 = p1 % r;
+  float2 acc0 = make_float2(0.f, 0.f), acc1 = make_float2(0.f, 0.f);
+  for (long nt = n0; nt < n1; nt += TN) {
+    const int cnt = (int)min((long)TN, n1 - nt);
+    __syncthreads();
+    for (int i = t; i < cnt * r; i += WT) {
+      Us[i / r][i % r] = U[nt * r + i];
+      Vs[i / r][i % r] = V[nt * r + i];
+    }
+    if (t < cnt) Gs[t] = G[b * N + nt + t];
+    __syncthreads();
+    if (p0 < rr)
+      for (int j = 0; j < cnt; ++j) {
+        const float w = Vs[j][k0] * Us[j][l0];
+        acc0.x = fmaf(w, Gs[j].x, acc0.x);
+        acc0.y = fmaf(w, Gs[j].y, acc0.y);
+      }
+    if (p1 < rr)
+      for (int j = 0; j < cnt; ++j) {
+        const float w = Vs[j][k1] * Us[j][l1];
+        acc1.x = fmaf(w, Gs[j].x, acc1.x);
+        acc1.y = fmaf(w, Gs[j].y, acc1.y);
+      }
+  }
+  float2 *P = partial + ((long)b * spans + sp) * rr;
+  if (p0 < rr) P[p0] = acc0;
+  if (p1 < rr) P[p1] = acc1;
+}
+
+// One wave per row: M = I + sum of the partials, inverse by Gauss-Jordan on [M | I] with partial pivoting.
+// A row whose M is singular to working precision gets a zero inverse (no correction) and flag[b] = 1.
+__global__ __launch_bounds__(64) void bk_woodbury_solve_kernel(const float2 *__restrict__ partial, int r, int spans,
+                                                               float2 *__restrict__ inv, int *__restrict__ flag) {
+  __shared__ float2 A[MAX_R][2 * MAX_R];
+  __shared__ float2 fac[MAX_R];
+  __shared__ int piv;
+  const long b = blockIdx.x;
+  const int lane = threadIdx.x, rr = r * r, w = 2 * r;
+  for (int i = lane; i < rr; i += 64) {
+    float2 s = make_float2(0.f, 0.f);
+    for (int sp = 0; sp < spans; ++sp) {
+      const float2 v = partial[((long)b * spans + sp) * rr + i];
+      s.x += v.x;
+      s.y += v.y;
+    }
+    const int k = i / r, l = i % r;
+    if (k == l) s.x += 1.0f;
+    A[k][l] = s;
+    A[k][r + l] = make_float2(k == l ? 1.0f : 0.0f, 0.0f);
+  }
+  __syncthreads();
+  bool singular = false;
+  for (int c = 0; c < r; ++c) {
+    if (lane == 0) {
+      int best = c;
+      float bm = -1.0f;
+      for (int i = c; i < r; ++i) {
+        const float m = fmaf(A[i][c].x, A[i][c].x, A[i][c].y * A[i][c].y);
+        if (m > bm) { bm = m; best = i; }
+      }
+      piv = (bm > 1e-30f) ? best : -1;
+    }
+    __syncthreads();
+    const int p = piv;
+    if (p < 0) { singular = true; break; }  // uniform
+    if (p != c)
+      for (int j = lane; j < w; j += 64) {
+        const float2 tmp = A[c][j];
+        A[c][j] = A[p][j];
+        A[p][j] = tmp;
+      }
+    __syncthreads();
+    const float2 d = A[c][c];
+    const float dn = 1.0f / fmaf(d.x, d.x, d.y * d.y);
+    const float2 dinv = make_float2(d.x * dn, -d.y * dn);
+    if (lane < r) fac[lane] = A[lane][c];
+    __syncthreads();
+    for (int j = lane; j < w; j += 64) A[c][j] = cmulf(A[c][j], dinv);
+    __syncthreads();
+    for (int q = lane; q < r * w; q += 64) {
+      const int i = q / w, j = q % w;
+      if (i != c) {
+        const float2 f = fac[i], pc = A[c][j];
+        A[i][j].x -= fmaf(f.x, pc.x, -f.y * pc.y);
+        A[i][j].y -= fmaf(f.x, pc.y, f.y * pc.x);
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = lane; i < rr; i += 64)
+    inv[b * rr + i] = singular ? make_float2(0.f, 0.f) : A[i / r][r + i % r];
+  if (lane == 0) flag[b] = singular ? 1 : 0;
+}
+
+// out[b][n] = G - G^2 * sum_{k,l} U[n][k] W[k][l] V[n][l]
+__global__ __launch_bounds__(WT) void bk_woodbury_apply_kernel(const float2 *__restrict__ G,
+                                                               const float *__restrict__ U,
+                                                               const float *__restrict__ V,
+                                                               const float2 *__restrict__ inv, long N, int r,
+                                                               float2 *__restrict__ out) {
+  __shared__ float2 Ws[MAX_R * MAX_R];
+  const long b = blockIdx.y;
+  const int rr = r * r;
+  for (int i = threadIdx.x; i < rr; i += WT) Ws[i] = inv[b * rr + i];
+  __syncthreads();
+  const long n = (long)blockIdx.x * WT + threadIdx.x;
+  if (n >= N) return;
+  float u[MAX_R], v[MAX_R];
+#pragma unroll
+  for (int k = 0; k < MAX_R; ++k) {
+    u[k] = k < r ? U[n * r + k] : 0.0f;
+    v[k] = k < r ? V[n * r + k] : 0.0f;
+  }
+  float2 q = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < MAX_R; ++k) {
+    if (k < r) {
+      float2 tk = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int l = 0; l < MAX_R; ++l)
+        if (l < r) {
+          tk.x = fmaf(Ws[k * r + l].x, v[l], tk.x);
+          tk.y = fmaf(Ws[k * r + l].y, v[l], tk.y);
+        }
+      q.x = fmaf(u[k], tk.x, q.x);
+      q.y = fmaf(u[k], tk.y, q.y);
+    }
+  }
+  const float2 g = G[b * N + n];
+  const float2 c = cmulf(cmulf(g, q), g);
+  out[b * N + n] = make_float2(g.x - c.x, g.y - c.y);
+}
+
+inline int gram_spans(int64_t N) { return (int)((N + GRAM_SPAN - 1) / GRAM_SPAN); }
+
+}  // namespace
+
+extern "C" {
+
+size_t bkcore_woodbury_workspace_bytes(int64_t B, int64_t N, int64_t r) {
+  if (B <= 0 || N <= 0 || r <= 0) return 0;
+  const size_t rr = (size_t)(r * r);
+  // gram partials, inverses, one flag per row (padded)
+  return ((size_t)B * gram_spans(N) * rr + (size_t)B * rr) * sizeof(float2) + (((size_t)B * sizeof(int) + 255) & ~(size_t)255);
+}
+
+int bkcore_woodbury_correct(const float *G, const float *U, const float *V, int64_t B, int64_t N, int64_t r,
+                            float *out, void *workspace, size_t workspace_bytes, void *stream) {
+  if (B < 0 || N < 0 || r < 0 || r > MAX_R) return BKCORE_EINVAL;
+  if (B == 0 || N == 0) return BKCORE_OK;
+  if (!G || !out || B > 65535) return BKCORE_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (r == 0) {
+    const hipError_t e = hipMemcpyAsync(out, G, (size_t)B * N * sizeof(float2), hipMemcpyDeviceToDevice, s);
+    return e == hipSuccess ? BKCORE_OK : BKCORE_ELAUNCH;
+  }
+  if (!U || !V) return BKCORE_EINVAL;
+  const size_t need = bkcore_woodbury_workspace_bytes(B, N, r);
+  if (!workspace || workspace_bytes < need) return BKCORE_EWORKSPACE;
+  const int spans = gram_spans(N);
+  const size_t rr = (size_t)(r * r);
+  float2 *partial = (float2 *)workspace;
+  float2 *inv = partial + (size_t)B * spans * rr;
+  int *flag = (int *)(inv + (size_t)B * rr);
+  if ((int64_t)B * spans > 2147483647LL) return BKCORE_EINVAL;
+  hipLaunchKernelGGL(bk_woodbury_gram_kernel, dim3((unsigned)(B * spans)), dim3(WT), 0, s, (const float2 *)G, U, V,
+                     (long)N, (int)r, spans, partial);
+  hipLaunchKernelGGL(bk_woodbury_solve_kernel, dim3((unsigned)B), dim3(64), 0, s, (const float2 *)partial, (int)r,
+                     spans, inv, flag);
+  hipLaunchKernelGGL(bk_woodbury_apply_kernel, dim3((unsigned)((N + WT - 1) / WT), (unsigned)B), dim3(WT), 0, s,
+                     (const float2 *)G, U, V, (const float2 *)inv, (long)N, (int)r, (float2 *)out);
+  return hipGetLastError() == hipSuccess ? BKCORE_OK : BKCORE_ELAUNCH;
+}
+
+}  // extern "C"
