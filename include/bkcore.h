@@ -195,7 +195,7 @@ int bkcore_cumsum(const float *x, float *y, int64_t outer, int64_t L, int64_t in
  * Replaces the Python loop over the batch in BirmanSchwingerCore.compute_semiseparable_resolvent,
  * src/models/birman_schwinger_core.py:567-604 (complex64 arithmetic as there, :563).
  *
- * G, out: B*N complex64; U, V: N*r floats, row-major (N, r) as SemiseparableMatrix.U / .V; r <= 22; B <= 65535.
+ * G, out: B*N complex64; U, V: N*r floats, row-major (N, r) as SemiseparableMatrix.U / .V; r <= 22.
  * A row whose r x r system is singular to working precision is returned uncorrected (the reference falls back to a
  * pseudo-inverse there, :584-586).  workspace: at least bkcore_woodbury_workspace_bytes(B, N, r) bytes.
  */

@@ -394,8 +394,11 @@ class FusedBKLayerFunction(torch.autograd.Function):
         v = v_pre.detach().float().contiguous()
         he = layer_prologue(v, h0_diag.detach(), v_max, torch.bfloat16)
         nb = max(N - 1, 0)
-        b = h0_super.detach().to(torch.bfloat16).reshape(-1, nb)
-        c = h0_sub.detach().to(torch.bfloat16).reshape(-1, nb)
+        if nb == 0:
+            b = c = torch.empty((B, 0), dtype=torch.bfloat16, device=v.device)
+        else:
+            b = h0_super.detach().to(torch.bfloat16).reshape(-1, nb)
+            c = h0_sub.detach().to(torch.bfloat16).reshape(-1, nb)
         if b.shape[0] != B:
             b = b.expand(B, -1)
         if c.shape[0] != B:

@@ -132,13 +132,13 @@ __global__ __launch_bounds__(WT) void bk_woodbury_apply_kernel(const float2 *__r
                                                                const float *__restrict__ U,
                                                                const float *__restrict__ V,
                                                                const float2 *__restrict__ inv, long N, int r,
-                                                               float2 *__restrict__ out) {
+                                                               long tiles, float2 *__restrict__ out) {
   __shared__ float2 Ws[MAX_R * MAX_R];
-  const long b = blockIdx.y;
+  const long b = blockIdx.x / tiles;
   const int rr = r * r;
   for (int i = threadIdx.x; i < rr; i += WT) Ws[i] = inv[b * rr + i];
   __syncthreads();
-  const long n = (long)blockIdx.x * WT + threadIdx.x;
+  const long n = (long)(blockIdx.x % tiles) * WT + threadIdx.x;
   if (n >= N) return;
   float u[MAX_R], v[MAX_R];
 #pragma unroll
@@ -183,7 +183,7 @@ int bkcore_woodbury_correct(const float *G, const float *U, const float *V, int6
                             float *out, void *workspace, size_t workspace_bytes, void *stream) {
   if (B < 0 || N < 0 || r < 0 || r > MAX_R) return BKCORE_EINVAL;
   if (B == 0 || N == 0) return BKCORE_OK;
-  if (!G || !out || B > 65535) return BKCORE_EINVAL;
+  if (!G || !out) return BKCORE_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (r == 0) {
     const hipError_t e = hipMemcpyAsync(out, G, (size_t)B * N * sizeof(float2), hipMemcpyDeviceToDevice, s);
@@ -197,13 +197,14 @@ int bkcore_woodbury_correct(const float *G, const float *U, const float *V, int6
   float2 *partial = (float2 *)workspace;
   float2 *inv = partial + (size_t)B * spans * rr;
   int *flag = (int *)(inv + (size_t)B * rr);
-  if ((int64_t)B * spans > 2147483647LL) return BKCORE_EINVAL;
+  const int64_t tiles = (N + WT - 1) / WT;
+  if ((int64_t)B * spans > 2147483647LL || B * tiles > 2147483647LL) return BKCORE_EINVAL;
   hipLaunchKernelGGL(bk_woodbury_gram_kernel, dim3((unsigned)(B * spans)), dim3(WT), 0, s, (const float2 *)G, U, V,
                      (long)N, (int)r, spans, partial);
   hipLaunchKernelGGL(bk_woodbury_solve_kernel, dim3((unsigned)B), dim3(64), 0, s, (const float2 *)partial, (int)r,
                      spans, inv, flag);
-  hipLaunchKernelGGL(bk_woodbury_apply_kernel, dim3((unsigned)((N + WT - 1) / WT), (unsigned)B), dim3(WT), 0, s,
-                     (const float2 *)G, U, V, (const float2 *)inv, (long)N, (int)r, (float2 *)out);
+  hipLaunchKernelGGL(bk_woodbury_apply_kernel, dim3((unsigned)(B * tiles)), dim3(WT), 0, s, (const float2 *)G, U, V,
+                     (const float2 *)inv, (long)N, (int)r, (long)tiles, (float2 *)out);
   return hipGetLastError() == hipSuccess ? BKCORE_OK : BKCORE_ELAUNCH;
 }
 

@@ -75,14 +75,15 @@ def _chain_unfused(v_pre, h0_diag, b, c, z, v_max, fclamp):
 
 
 @pytest.mark.parametrize("B,N,fclamp,with_gG", [(4, 64, 5.0, False), (8, 256, 0.3, True), (2, 4500, None, False),
-                                                (3, 33, 0.3, True)])
+                                                (3, 33, 0.3, True), (3, 1, 5.0, False)])
 def test_fused_chain_forward_backward(B, N, fclamp, with_gG):
     _need_gpu()
     import bkcore
     g = torch.Generator(device="cuda").manual_seed(N)
-    v0 = 2.0 * torch.randn(B, N, generator=g, device="cuda")
+    v0 = 2.0 * torch.randn(B, max(N, 3), generator=g, device="cuda")
     v0[0, 1] = float("nan")
     v0[-1, 2] = float("inf")
+    v0 = v0[:, :N].contiguous()
     h0 = torch.full((1, N), -2.0, device="cuda") + 0.1 * torch.randn(1, N, generator=g, device="cuda")
     b = 1.0 + 0.1 * torch.randn(1, N - 1, generator=g, device="cuda")
     c = 1.0 + 0.1 * torch.randn(1, N - 1, generator=g, device="cuda")
@@ -110,7 +111,8 @@ def test_fused_chain_forward_backward(B, N, fclamp, with_gG):
     torch.autograd.backward(outs_b, cot)
     ga, gb = va.grad, vb.grad
     assert gb.dtype == torch.float32 and gb.shape == (B, N)
-    assert float(gb[0, 1]) == 0.0 and float(gb[-1, 2]) == 0.0          # non-finite v_pre: no gradient
+    if N >= 3:
+        assert float(gb[0, 1]) == 0.0 and float(gb[-1, 2]) == 0.0      # non-finite v_pre: no gradient
     # same formula; a last-bit difference before the bfloat16 rounding of the operator's gradient can move one step
     d = (ga - gb).abs()
     tol = 2.0 ** -7 * ga.abs() + 1e-6
