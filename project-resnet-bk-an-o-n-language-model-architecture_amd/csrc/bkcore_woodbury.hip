@@ -21,20 +21,32 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
   return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
 }
 
-// partial[b][s][k*r + l] = sum over the positions n of span s of V[n][k] U[n][l] G[b][n]
+// partial[b][s][k*r + l] = sum over the positions n of span s of V[n][k] U[n][l] G[b][n].
+// A thread owns a strip (k; l0 .. l0+3): per position one 16-byte LDS read of U, one read of V, one of G for four
+// (k, l) pairs.  The r * ceil(r/4) strips are replicated over as many groups of threads as fit the workgroup, each
+// group taking every rep-th staged position; the groups' sums are added through LDS at the end.
+constexpr int UROW = 24;  // floats per staged row of U (16-byte aligned quads, zero beyond r)
 __global__ __launch_bounds__(WT) void bk_woodbury_gram_kernel(const float2 *__restrict__ G,
                                                               const float *__restrict__ U,
                                                               const float *__restrict__ V, long N, int r, int spans,
                                                               float2 *__restrict__ partial) {
-  __shared__ float Us[TN][MAX_R + 1], Vs[TN][MAX_R + 1];
+  __shared__ __align__(16) float Us[TN][UROW];
+  __shared__ float Vs[TN][MAX_R + 1];
   __shared__ float2 Gs[TN];
+  __shared__ float2 red[WT][4];
   const long b = blockIdx.x / spans;
   const int sp = blockIdx.x % spans;
   const long n0 = (long)sp * GRAM_SPAN, n1 = min(N, n0 + GRAM_SPAN);
   const int t = threadIdx.x, rr = r * r;
-  const int p0 = t, p1 = t + WT;
-  const int k0 = p0 / r, l0 = p0 % r, k1 = p1 / r, l1 = p1 % r;
-  float2 acc0 = make_float2(0.f, 0.f), acc1 = make_float2(0.f, 0.f);
+  const int lq = (r + 3) / 4, nstr = r * lq;
+  const int rep = WT / nstr;                 // >= 1 because r <= 22
+  const int strip = t % nstr, sub = t / nstr;
+  const bool live = sub < rep;
+  const int k = strip / lq, l0 = (strip % lq) * 4;
+  for (int i = t; i < TN * UROW; i += WT) (&Us[0][0])[i] = 0.0f;
+  float2 acc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = make_float2(0.f, 0.f);
   for (long nt = n0; nt < n1; nt += TN) {
     const int cnt = (int)min((long)TN, n1 - nt);
     __syncthreads();
@@ -44,22 +56,33 @@ __global__ __launch_bounds__(WT) void bk_woodbury_gram_kernel(const float2 *__re
     }
     if (t < cnt) Gs[t] = G[b * N + nt + t];
     __syncthreads();
-    if (p0 < rr)
-      for (int j = 0; j < cnt; ++j) {
-        const float w = Vs[j][k0] * Us[j][l0];
-        acc0.x = fmaf(w, Gs[j].x, acc0.x);
-        acc0.y = fmaf(w, Gs[j].y, acc0.y);
-      }
-    if (p1 < rr)
-      for (int j = 0; j < cnt; ++j) {
-        const float w = Vs[j][k1] * Us[j][l1];
-        acc1.x = fmaf(w, Gs[j].x, acc1.x);
-        acc1.y = fmaf(w, Gs[j].y, acc1.y);
+    if (live)
+      for (int j = sub; j < cnt; j += rep) {
+        const float4 u4 = *reinterpret_cast<const float4 *>(&Us[j][l0]);
+        const float vk = Vs[j][k];
+        const float2 g = Gs[j];
+        const float vgx = vk * g.x, vgy = vk * g.y;
+        acc[0].x = fmaf(u4.x, vgx, acc[0].x); acc[0].y = fmaf(u4.x, vgy, acc[0].y);
+        acc[1].x = fmaf(u4.y, vgx, acc[1].x); acc[1].y = fmaf(u4.y, vgy, acc[1].y);
+        acc[2].x = fmaf(u4.z, vgx, acc[2].x); acc[2].y = fmaf(u4.z, vgy, acc[2].y);
+        acc[3].x = fmaf(u4.w, vgx, acc[3].x); acc[3].y = fmaf(u4.w, vgy, acc[3].y);
       }
   }
-  float2 *P = partial + ((long)b * spans + sp) * rr;
-  if (p0 < rr) P[p0] = acc0;
-  if (p1 < rr) P[p1] = acc1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[t][e] = acc[e];
+  __syncthreads();
+  if (sub == 0) {
+    float2 *P = partial + ((long)b * spans + sp) * rr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float2 sum = acc[e];
+      for (int q = 1; q < rep; ++q) {
+        sum.x += red[q * nstr + strip][e].x;
+        sum.y += red[q * nstr + strip][e].y;
+      }
+      if (l0 + e < r) P[k * r + l0 + e] = sum;
+    }
+  }
 }
 
 // One wave per row: M = I + sum of the partials, inverse by Gauss-Jordan on [M | I] with partial pivoting.
@@ -127,7 +150,8 @@ __global__ __launch_bounds__(64) void bk_woodbury_solve_kernel(const float2 *__r
   if (lane == 0) flag[b] = singular ? 1 : 0;
 }
 
-// out[b][n] = G - G^2 * sum_{k,l} U[n][k] W[k][l] V[n][l]
+// out[b][n] = G - G^2 * sum_{k,l} U[n][k] W[k][l] V[n][l]; NP positions per thread
+constexpr int NP = 1;  // 2 measured slower (registers)
 __global__ __launch_bounds__(WT) void bk_woodbury_apply_kernel(const float2 *__restrict__ G,
                                                                const float *__restrict__ U,
                                                                const float *__restrict__ V,
@@ -138,32 +162,53 @@ __global__ __launch_bounds__(WT) void bk_woodbury_apply_kernel(const float2 *__r
   const int rr = r * r;
   for (int i = threadIdx.x; i < rr; i += WT) Ws[i] = inv[b * rr + i];
   __syncthreads();
-  const long n = (long)(blockIdx.x % tiles) * WT + threadIdx.x;
-  if (n >= N) return;
-  float u[MAX_R], v[MAX_R];
+  const long nb = (long)(blockIdx.x % tiles) * (WT * NP) + threadIdx.x;
+  float u[NP][MAX_R], v[NP][MAX_R];
 #pragma unroll
-  for (int k = 0; k < MAX_R; ++k) {
-    u[k] = k < r ? U[n * r + k] : 0.0f;
-    v[k] = k < r ? V[n * r + k] : 0.0f;
+  for (int e = 0; e < NP; ++e) {
+    const long n = nb + (long)e * WT;
+#pragma unroll
+    for (int k = 0; k < MAX_R; ++k) {
+      const bool ok = k < r && n < N;
+      u[e][k] = ok ? U[n * r + k] : 0.0f;
+      v[e][k] = ok ? V[n * r + k] : 0.0f;
+    }
   }
-  float2 q = make_float2(0.f, 0.f);
+  float2 q[NP];
+#pragma unroll
+  for (int e = 0; e < NP; ++e) q[e] = make_float2(0.f, 0.f);
 #pragma unroll
   for (int k = 0; k < MAX_R; ++k) {
     if (k < r) {
-      float2 tk = make_float2(0.f, 0.f);
+      float2 tk[NP];
+#pragma unroll
+      for (int e = 0; e < NP; ++e) tk[e] = make_float2(0.f, 0.f);
 #pragma unroll
       for (int l = 0; l < MAX_R; ++l)
         if (l < r) {
-          tk.x = fmaf(Ws[k * r + l].x, v[l], tk.x);
-          tk.y = fmaf(Ws[k * r + l].y, v[l], tk.y);
+          const float2 w = Ws[k * r + l];
+#pragma unroll
+          for (int e = 0; e < NP; ++e) {
+            tk[e].x = fmaf(w.x, v[e][l], tk[e].x);
+            tk[e].y = fmaf(w.y, v[e][l], tk[e].y);
+          }
         }
-      q.x = fmaf(u[k], tk.x, q.x);
-      q.y = fmaf(u[k], tk.y, q.y);
+#pragma unroll
+      for (int e = 0; e < NP; ++e) {
+        q[e].x = fmaf(u[e][k], tk[e].x, q[e].x);
+        q[e].y = fmaf(u[e][k], tk[e].y, q[e].y);
+      }
     }
   }
-  const float2 g = G[b * N + n];
-  const float2 c = cmulf(cmulf(g, q), g);
-  out[b * N + n] = make_float2(g.x - c.x, g.y - c.y);
+#pragma unroll
+  for (int e = 0; e < NP; ++e) {
+    const long n = nb + (long)e * WT;
+    if (n < N) {
+      const float2 g = G[b * N + n];
+      const float2 c = cmulf(cmulf(g, q[e]), g);
+      out[b * N + n] = make_float2(g.x - c.x, g.y - c.y);
+    }
+  }
 }
 
 inline int gram_spans(int64_t N) { return (int)((N + GRAM_SPAN - 1) / GRAM_SPAN); }
@@ -197,7 +242,7 @@ int bkcore_woodbury_correct(const float *G, const float *U, const float *V, int6
   float2 *partial = (float2 *)workspace;
   float2 *inv = partial + (size_t)B * spans * rr;
   int *flag = (int *)(inv + (size_t)B * rr);
-  const int64_t tiles = (N + WT - 1) / WT;
+  const int64_t tiles = (N + WT * NP - 1) / (WT * NP);
   if ((int64_t)B * spans > 2147483647LL || B * tiles > 2147483647LL) return BKCORE_EINVAL;
   hipLaunchKernelGGL(bk_woodbury_gram_kernel, dim3((unsigned)(B * spans)), dim3(WT), 0, s, (const float2 *)G, U, V,
                      (long)N, (int)r, spans, partial);
