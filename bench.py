@@ -223,7 +223,19 @@ def main():
                 f_med, f_min = per_iter(lambda: bkcore.bk_forward(ad, b, c, z))
             out["events_100_iters"] = {"fwd_bwd_ms_median": fb_med, "fwd_bwd_ms_min": fb_min,
                                        "fwd_ms_median": f_med, "fwd_ms_min": f_min}
+            # the layer's chain around the operator (tanh saturation + bfloat16 cast in front, clamp behind, and the
+            # whole backward chain), two library launches each way, at the same size
+            h0 = torch.full((1, N), -2.0, device=device)
+            vpre = torch.randn(B, N, device=device)
+
+            def layer_chain():
+                vv = vpre.detach().requires_grad_(True)
+                ff, _ = bkcore.FusedBKLayerFunction.apply(vv, h0, b[:1], c[:1], z, 5.0, 5.0)
+                torch.autograd.backward((ff,), (gfeat,))
+            t_chain = timed(layer_chain, 10)
+            del h0, vpre
             out["secondary"] = {
+                "layer_chain_fused_fwd_bwd_ms": t_chain * 1e3,
                 "analytic_backward_ms": t_ana * 1e3,
                 "analytic_backward_note": "grad for he_diag, h0_super, h0_sub; re-runs the forward inside",
                 "long_context_B16_N1048576": {"fwd_ms": t3f * 1e3, "bwd_ms": t3b * 1e3,
