@@ -1894,17 +1894,37 @@ __device__ __forceinline__ uint16_t to_bf16_rne(float x) {
 }
 __device__ __forceinline__ float bf16_round(float x) { return __uint_as_float((unsigned)to_bf16_rne(x) << 16); }
 
-template <bool OUT_BF16>
+template <bool OUT_BF16, bool VEC>  // VEC: N and ldv multiples of 4, 16-byte aligned rows: four elements per thread
 __global__ __launch_bounds__(256) void bk_layer_prologue_kernel(const float *__restrict__ v_pre, long ldv,
                                                                 const float *__restrict__ h0_diag, float v_max,
                                                                 float inv_v_max, long B, long N,
                                                                 void *__restrict__ he_diag) {
   for (long row = blockIdx.y; row < B; row += gridDim.y) {
     const float *__restrict__ v = v_pre + row * ldv;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
-      const float he = h0_diag[i] + saturate_potential(v[i], v_max, inv_v_max);
-      if (OUT_BF16) reinterpret_cast<uint16_t *>(he_diag)[row * N + i] = to_bf16_rne(he);
-      else reinterpret_cast<float *>(he_diag)[row * N + i] = he;
+    if (VEC) {
+      for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < N / 4; q += (long)gridDim.x * blockDim.x) {
+        const float4 vv = reinterpret_cast<const float4 *>(v)[q];
+        const float4 hh = reinterpret_cast<const float4 *>(h0_diag)[q];
+        float4 he;
+        he.x = hh.x + saturate_potential(vv.x, v_max, inv_v_max);
+        he.y = hh.y + saturate_potential(vv.y, v_max, inv_v_max);
+        he.z = hh.z + saturate_potential(vv.z, v_max, inv_v_max);
+        he.w = hh.w + saturate_potential(vv.w, v_max, inv_v_max);
+        if (OUT_BF16) {
+          uint2 pk;
+          pk.x = (unsigned)to_bf16_rne(he.x) | ((unsigned)to_bf16_rne(he.y) << 16);
+          pk.y = (unsigned)to_bf16_rne(he.z) | ((unsigned)to_bf16_rne(he.w) << 16);
+          reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(he_diag) + row * N)[q] = pk;
+        } else {
+          reinterpret_cast<float4 *>(reinterpret_cast<float *>(he_diag) + row * N)[q] = he;
+        }
+      }
+    } else {
+      for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+        const float he = h0_diag[i] + saturate_potential(v[i], v_max, inv_v_max);
+        if (OUT_BF16) reinterpret_cast<uint16_t *>(he_diag)[row * N + i] = to_bf16_rne(he);
+        else reinterpret_cast<float *>(he_diag)[row * N + i] = he;
+      }
     }
   }
 }
@@ -2187,12 +2207,19 @@ int bkcore_layer_prologue(const float *v_pre, int64_t ldv, const float *h0_diag,
   if (gx > 1024) gx = 1024;
   const dim3 grid((unsigned)gx, (unsigned)(B > 32768 ? 32768 : B)), block(256);
   const float inv = 1.0f / v_max;
-  if (out_dtype == BKCORE_BF16)
-    hipLaunchKernelGGL((bk_layer_prologue_kernel<true>), grid, block, 0, s, v_pre, (long)ldv, h0_diag, v_max, inv,
-                       (long)B, (long)N, he_diag);
-  else
-    hipLaunchKernelGGL((bk_layer_prologue_kernel<false>), grid, block, 0, s, v_pre, (long)ldv, h0_diag, v_max, inv,
-                       (long)B, (long)N, he_diag);
+  const bool vec = (N % 4) == 0 && (ldv % 4) == 0 && ((uintptr_t)v_pre % 16) == 0 && ((uintptr_t)h0_diag % 16) == 0 &&
+                   ((uintptr_t)he_diag % 16) == 0;
+#define BK_PRO(BF, VEC)                                                                                              \
+  hipLaunchKernelGGL((bk_layer_prologue_kernel<BF, VEC>), grid, block, 0, s, v_pre, (long)ldv, h0_diag, v_max, inv,  \
+                     (long)B, (long)N, he_diag)
+  if (out_dtype == BKCORE_BF16) {
+    if (vec) BK_PRO(true, true);
+    else BK_PRO(true, false);
+  } else {
+    if (vec) BK_PRO(false, true);
+    else BK_PRO(false, false);
+  }
+#undef BK_PRO
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) {
     g_last_hip_error = (int)err;
