@@ -163,13 +163,21 @@ __global__ __launch_bounds__(LT) void bk_layer_epilogue_bwd_wave_kernel(const fl
       a1[q][e] = sc * W[2 * d + 1];
       s0[q][e] = s1[q][e] = sb[q][e] = 0.0f;
     }
-  for (long i = r0 + wave; i < r1; i += LT / 64) {
+  // two positions per pass, both rows' loads issued before either is used
+  constexpr int WS = LT / 64;
+  for (long i = r0 + wave; i < r1; i += 2 * WS) {
+    const long i2 = i + WS;
+    const bool two = i2 < r1;  // uniform over the wave
     const float f0 = feat[2 * i], f1 = feat[2 * i + 1];
+    const float h0 = two ? feat[2 * i2] : 0.0f, h1 = two ? feat[2 * i2 + 1] : 0.0f;
     const float4 *__restrict__ row = reinterpret_cast<const float4 *>(go + i * D) + lane;
-    float4 g[Q];
+    const float4 *__restrict__ row2 = reinterpret_cast<const float4 *>(go + (two ? i2 : i) * D) + lane;
+    float4 g[Q], g2[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) g[q] = row[64 * q];
-    float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) g2[q] = row2[64 * q];
+    float p0 = 0.0f, p1 = 0.0f, q0 = 0.0f, q1 = 0.0f;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       const float ge[4] = {g[q].x, g[q].y, g[q].z, g[q].w};
@@ -182,9 +190,28 @@ __global__ __launch_bounds__(LT) void bk_layer_epilogue_bwd_wave_kernel(const fl
         sb[q][e] += ge[e];
       }
     }
+    if (two) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const float ge[4] = {g2[q].x, g2[q].y, g2[q].z, g2[q].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          q0 = fmaf(ge[e], a0[q][e], q0);
+          q1 = fmaf(ge[e], a1[q][e], q1);
+          s0[q][e] = fmaf(ge[e], h0, s0[q][e]);
+          s1[q][e] = fmaf(ge[e], h1, s1[q][e]);
+          sb[q][e] += ge[e];
+        }
+      }
+    }
     p0 = wave_total_in_lane63(p0);
     p1 = wave_total_in_lane63(p1);
-    if (lane == 63) *reinterpret_cast<float2 *>(gfeat + 2 * i) = make_float2(p0, p1);
+    q0 = wave_total_in_lane63(q0);
+    q1 = wave_total_in_lane63(q1);
+    if (lane == 63) {
+      *reinterpret_cast<float2 *>(gfeat + 2 * i) = make_float2(p0, p1);
+      if (two) *reinterpret_cast<float2 *>(gfeat + 2 * i2) = make_float2(q0, q1);
+    }
   }
   // the four waves' column sums are combined in LDS (fixed order) into one record per workgroup
   __shared__ float part[LT / 64][3 * D];
