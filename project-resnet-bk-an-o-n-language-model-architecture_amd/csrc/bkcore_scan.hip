@@ -19,7 +19,7 @@ namespace {
 constexpr int ST = 256;   // threads per workgroup
 constexpr int TC = 32;    // columns per workgroup (strided kernel)
 constexpr int NSEG = ST / TC;
-constexpr int SEG = 8;    // consecutive sequence positions per thread
+constexpr int SEG = 16;   // consecutive sequence positions per thread
 
 template <bool REVERSE>
 __global__ __launch_bounds__(ST) void bk_cumsum_strided_kernel(const float *__restrict__ x, float *__restrict__ y,
