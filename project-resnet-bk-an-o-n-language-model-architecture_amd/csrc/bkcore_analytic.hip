@@ -483,7 +483,10 @@ int bkcore_backward_analytic(const float *a, int64_t lda, const float *b, int64_
   }
 #undef BK_LAUNCH_ADJ
   const hipError_t err = hipGetLastError();
-  if (err != hipSuccess) return BKCORE_ELAUNCH;
+  if (err != hipSuccess) {
+    bkcore_internal_set_hip_error((int)err);
+    return BKCORE_ELAUNCH;
+  }
   return BKCORE_OK;
 }
 

@@ -11,4 +11,18 @@ extern "C" __attribute__((visibility("hidden"))) int bkcore_internal_forward_sav
     const float *a, int64_t lda, const float *b, int64_t ldb, const float *c, int64_t ldc, const float *z_dev,
     float z_re, float z_im, int64_t B, int64_t N, float *G, void *workspace, void *state, unsigned flags, void *stream,
     float *save_r, float *save_s);
+
+// Launches of the ratio-form forward (bkcore_ratio.hip); errors are left for the caller's hipGetLastError().
+// mode 0: one workgroup per row (save != 0: the variant that also stores r, s and writes G_raw); mode 1 / 2: per-segment
+// products / per-segment outputs of rows cut into S segments of seg_ch chunks, around bkcore_internal_ratio_combine.
+extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_ratio_forward(
+    int in_dtype, int phi_exact, int mode, int save, const void *a, int64_t lda, const void *b, int64_t ldb,
+    const void *c, int64_t ldc, const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G,
+    float *features, void *ws, void *state, int call_id, unsigned flags, float fclamp, int S, int seg_ch, float *save_r,
+    float *save_s, void *stream);
+extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_ratio_combine(int64_t B, int64_t N, void *ws,
+                                                                                   void *state, int call_id, int S,
+                                                                                   void *stream);
+// Records the HIP error code that bkcore_last_hip_error() reports (per thread).
+extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_set_hip_error(int code);
 #endif

@@ -9,6 +9,15 @@
 #include <stdint.h>
 
 #include "../../include/bkcore.h"
+#include "bkcore_internal.h"
+
+// BKCORE_OK, or BKCORE_ELAUNCH with the HIP code recorded for bkcore_last_hip_error()
+static inline int bk_launch_status() {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return BKCORE_OK;
+  bkcore_internal_set_hip_error((int)e);
+  return BKCORE_ELAUNCH;
+}
 
 namespace {
 
@@ -302,7 +311,7 @@ int bkcore_layer_epilogue(const float *features, const float *weight, const floa
   else if (residual) BK_EPI(false, true);
   else BK_EPI(false, false);
 #undef BK_EPI
-  return hipGetLastError() == hipSuccess ? BKCORE_OK : BKCORE_ELAUNCH;
+  return bk_launch_status();
 }
 
 size_t bkcore_layer_epilogue_backward_workspace_bytes(int64_t n, int64_t D) {
@@ -345,7 +354,7 @@ int bkcore_layer_epilogue_backward(const float *grad_out, const float *features,
     hipLaunchKernelGGL(bk_layer_epilogue_bwd_finish_kernel, dim3((unsigned)((D + 31) / 32)), dim3(LT), 0, s,
                        (const float *)workspace, nblk, weight, bias, scale, (int)D, grad_weight, grad_bias,
                        grad_scale);
-  return hipGetLastError() == hipSuccess ? BKCORE_OK : BKCORE_ELAUNCH;
+  return bk_launch_status();
 }
 
 }  // extern "C"

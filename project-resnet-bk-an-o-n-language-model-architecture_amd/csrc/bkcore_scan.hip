@@ -13,6 +13,15 @@
 #include <stdint.h>
 
 #include "../../include/bkcore.h"
+#include "bkcore_internal.h"
+
+// BKCORE_OK, or BKCORE_ELAUNCH with the HIP code recorded for bkcore_last_hip_error()
+static inline int bk_launch_status() {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return BKCORE_OK;
+  bkcore_internal_set_hip_error((int)e);
+  return BKCORE_ELAUNCH;
+}
 
 namespace {
 
@@ -189,5 +198,5 @@ extern "C" int bkcore_cumsum(const float *x, float *y, int64_t outer, int64_t L,
       hipLaunchKernelGGL((bk_cumsum_strided_kernel<false>), grid, dim3(ST), 0, s, x, y, (long)L, (long)inner,
                          (long)col_tiles, S, (long)part_len);
   }
-  return hipGetLastError() == hipSuccess ? BKCORE_OK : BKCORE_ELAUNCH;
+  return bk_launch_status();
 }

@@ -9,6 +9,15 @@
 #include <stdint.h>
 
 #include "../../include/bkcore.h"
+#include "bkcore_internal.h"
+
+// BKCORE_OK, or BKCORE_ELAUNCH with the HIP code recorded for bkcore_last_hip_error()
+static inline int bk_launch_status() {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return BKCORE_OK;
+  bkcore_internal_set_hip_error((int)e);
+  return BKCORE_ELAUNCH;
+}
 
 namespace {
 
@@ -232,6 +241,7 @@ int bkcore_woodbury_correct(const float *G, const float *U, const float *V, int6
   hipStream_t s = (hipStream_t)stream;
   if (r == 0) {
     const hipError_t e = hipMemcpyAsync(out, G, (size_t)B * N * sizeof(float2), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) bkcore_internal_set_hip_error((int)e);
     return e == hipSuccess ? BKCORE_OK : BKCORE_ELAUNCH;
   }
   if (!U || !V) return BKCORE_EINVAL;
@@ -250,7 +260,7 @@ int bkcore_woodbury_correct(const float *G, const float *U, const float *V, int6
                      spans, inv, flag);
   hipLaunchKernelGGL(bk_woodbury_apply_kernel, dim3((unsigned)(B * tiles)), dim3(WT), 0, s, (const float2 *)G, U, V,
                      (const float2 *)inv, (long)N, (int)r, (long)tiles, (float2 *)out);
-  return hipGetLastError() == hipSuccess ? BKCORE_OK : BKCORE_ELAUNCH;
+  return bk_launch_status();
 }
 
 }  // extern "C"
