@@ -23,6 +23,8 @@ extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_ratio_forw
 extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_ratio_combine(int64_t B, int64_t N, void *ws,
                                                                                    void *state, int call_id, int S,
                                                                                    void *stream);
+// Elements per chunk of the ratio-form kernel (its workgroup size x 16).
+extern "C" __attribute__((visibility("hidden"))) int bkcore_internal_ratio_chunk(void);
 // Records the HIP error code that bkcore_last_hip_error() reports (per thread).
 extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_set_hip_error(int code);
 #endif

@@ -1177,13 +1177,12 @@ __global__ __launch_bounds__(256) void bk_layer_backward_ref_kernel(const float2
 thread_local int g_last_hip_error = 0;
 int g_call_counter = 0;
 
-inline int chunks_of(int64_t N) { return (int)((N + CHUNK - 1) / CHUNK); }
-
-// How a (B, N) problem is cut: segments per row (1 = one workgroup per row) and chunks per segment.  Rows are cut
+// How a (B, N) problem is cut: segments per row (1 = one workgroup per row) and chunks per segment, in chunks of
+// `chunk` elements (the tile of the kernel that will run: the ratio-form kernel's or the scan kernel's).  Rows are cut
 // only when there are too few of them to occupy half of the 256 CUs and they are long enough (measured break-even:
 // about 140 rows).
-inline void split_plan(int64_t B, int64_t N, int &S, int &seg_ch) {
-  const int nch = chunks_of(N);
+inline void split_plan(int64_t B, int64_t N, int chunk, int &S, int &seg_ch) {
+  const int nch = (int)((N + chunk - 1) / chunk);
   S = 1;
   seg_ch = nch;
   if (B > 128 || nch < 8) return;  // up to 256 rows run as one round of one workgroup per CU, which is faster
@@ -1221,7 +1220,8 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
                      z_im, (long)B, (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id,     \
                      SECOND, flags, fclamp, (float2 *)save_r, (float2 *)save_s)
   int S = 1, seg_ch = 0;
-  if (state && !SAVE) split_plan(B, N, S, seg_ch);
+  if (state && !SAVE)
+    split_plan(B, N, (flags & BKCORE_FLAG_SCAN_PATH) ? CHUNK : bkcore_internal_ratio_chunk(), S, seg_ch);
   if (S > 1 && !(flags & BKCORE_FLAG_SCAN_PATH)) {
     // few long rows, ratio form: segment products, combine, segment outputs, then the (normally empty) launch of
     // the scan kernel for rows whose checks failed
@@ -1315,8 +1315,10 @@ extern "C" {
 
 size_t bkcore_workspace_bytes(int64_t B, int64_t N) {
   if (B <= 0 || N <= 0) return 0;
-  int S = 1, seg_ch = 0;
-  split_plan(B, N, S, seg_ch);
+  int S = 1, S2 = 1, seg_ch = 0;  // whichever first launch runs: room for the larger number of segment records
+  split_plan(B, N, bkcore_internal_ratio_chunk(), S, seg_ch);
+  split_plan(B, N, CHUNK, S2, seg_ch);
+  if (S2 > S) S = S2;
   const size_t seg_records = S > 1 ? (size_t)B * (size_t)S * SEG_INFO * sizeof(float) : 0;
   return rowflag_bytes(B) + lane_state_bytes(B, N) + seg_records;
 }

@@ -4,6 +4,17 @@
 
 namespace {
 
+// Tile of the ratio-form kernel: RT threads per workgroup, E elements per thread per chunk.  The workspace layout
+// (rowflag_bytes, lane_state_bytes) stays that of the scan kernel's tile.
+#ifndef BK_RATIO_T
+#define BK_RATIO_T 256
+#endif
+constexpr int RT = BK_RATIO_T;
+constexpr int RCHUNK = RT * E;
+constexpr int RWAVES = RT / 64;
+constexpr int RO_PAD = RCHUNK + RCHUNK / 16 + 8;
+static_assert(RT % 64 == 0 && RT >= 64 && RT <= 256, "whole waves, at most the scan kernel's workgroup");
+
 
 // ---- single-sweep forward in ratio form ------------------------------------------------------------------------
 // The same numbers from a different evaluation order.  With r_i = theta_{i+1}/theta_i and s_m = phi_m/phi_{m+1} the
@@ -20,14 +31,54 @@ namespace {
 // chunk -- and the only state carried from chunk to chunk is that running product, so the row is read ONCE
 // (chunks right -> left): 12 bytes in, 16 out per element, no lane states.
 #ifndef BK_RATIO_WAVES
-#define BK_RATIO_WAVES 2
+#define BK_RATIO_WAVES 3
+#endif
+// Scheduling fence every BK_SCHED_GROUP chain steps (0: none): keeps the compiler from hoisting the LDS reads of all
+// 64 steps of a chunk to the front, which costs more registers than 3 waves per SIMD leave.
+#ifndef BK_SCHED_GROUP
+#define BK_SCHED_GROUP 0
+#endif
+#if BK_SCHED_GROUP > 0
+#define BK_SCHED_FENCE(j) do { if (((j) % BK_SCHED_GROUP) == BK_SCHED_GROUP - 1) __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define BK_SCHED_FENCE(j) do { } while (0)
+#endif
+// development: BK_RATIO_STAMPS=1 writes s_memtime stamps of wave 0 at the phase boundaries of every chunk into the
+// (otherwise unused) lane-state region of the workspace: 16 slots of 8 bytes per (row, chunk)
+#ifndef BK_RATIO_STAMPS
+#define BK_RATIO_STAMPS 0
+#endif
+#if BK_RATIO_STAMPS
+#define BK_STAMP(k)                                                                                                  \
+  if ((BK_RATIO_STAMPS >> (k)) & 1) do {                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    const unsigned long long tm_ = __builtin_amdgcn_s_memtime();                                                     \
+    if (threadIdx.x == 0)                                                                                            \
+      reinterpret_cast<unsigned long long *>(ws + rowflag_bytes(B))[((row * nch + ch) * 16) + (k)] = tm_;            \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+  } while (0)
+#else
+#define BK_STAMP(k) do { } while (0)
+#endif
+#ifndef BK_RATIO_STAGGER
+#define BK_RATIO_STAGGER 0
+#endif
+#ifndef BK_RATIO_EXPERIMENT
+#define BK_RATIO_EXPERIMENT 0
+#endif
+#ifndef BK_RATIO_PREFETCH
+#define BK_RATIO_PREFETCH 1   // raw inputs of the next chunk held in registers during the current chunk's arithmetic
 #endif
 constexpr int RH = 16;                          // warm-up length = halo staged on both sides of a chunk
 #ifndef BK_RH_COARSE
 #define BK_RH_COARSE 8
 #endif
 constexpr int RH_COARSE = BK_RH_COARSE;         // leading warm-up steps taken in the coarse form
-constexpr int RN = CHUNK + 2 * RH;              // staged elements per chunk
+#ifndef BK_RH_FULL
+#define BK_RH_FULL 4
+#endif
+constexpr int RH_FULL = BK_RH_FULL;             // trailing warm-up steps taken as full steps
+constexpr int RN = RCHUNK + 2 * RH;              // staged elements per chunk
 constexpr int RAL_PAD = RN + RN / E + 8;        // float2 entries, index q + q/E
 constexpr int RK_PAD = RN + 1 + (RN + 1) / E + 8;
 
@@ -65,15 +116,15 @@ __device__ __forceinline__ Prod prod_dpp(const Prod &p) {  // identity where the
 struct SharedR {
   union {
     struct {
-      float2 al_s[RAL_PAD];  // regularised diagonal a' of elements base - RH .. base + CHUNK + RH - 1
+      float2 al_s[RAL_PAD];  // regularised diagonal a' of elements base - RH .. base + RCHUNK + RH - 1
       float k_s[RK_PAD];     // k_{i-1} for the same elements, plus one more
     } in;
-    float2 out_s[O_PAD];     // G of one chunk for coalesced stores
+    float2 out_s[RO_PAD];     // G of one chunk for coalesced stores
   } u;
-  float4 wedge[2][WAVES];    // last lane of each wave: theta warm-up result (xy) and phi end value (zw), for the
+  float4 wedge[2][RWAVES];    // last lane of each wave: theta warm-up result (xy) and phi end value (zw), for the
                              // first lane of the next wave
   float4 edge[2];            // the same from the first lane of the chunk to the right
-  Prod tot[2][WAVES];
+  Prod tot[2][RWAVES];
   Prod carry[2];
 };
 
@@ -106,25 +157,58 @@ __device__ __forceinline__ void store_lane_block(float2 *__restrict__ dst, const
 }
 
 // One step of either ratio map: r = al - k * om_prev; returns om(r) and hands back r and 1/r.  The reciprocal of
-// |r|^2 is refined by one Newton step and the clamp factor exp(g) is an exp2 of a tiny argument: the hardware log
-// and exp2 round with a bias of a fraction of an ulp, which is harmless inside the contracting recurrence and in g,
-// but would add up linearly over the N factors of the product if 1/|r|^2 were formed as exp2(-log2 |r|^2).
-__device__ __forceinline__ float2 ratio_step(float2 al, float k, float2 om, float2 &r, float2 &inv) {
+// |r|^2 is refined by one Newton step: the hardware reciprocal rounds with a bias of a fraction of an ulp, which would
+// add up linearly over the N factors of the product.
+// Clamp factor exp(g(d)), d = -ln|r|: g = 88 tanh(d/88) - d = -88 (u^3/3 - 2u^5/15 + ...), u = d/88.  With
+// Ln = log2 |r|^2 (one hardware log) u = -c Ln, c = ln2/176, so g = WALL_A Ln^3 - WALL_B Ln^5 and
+//     exp(g) = 1 + Ln^3 (WALL_A - WALL_B Ln^2 + (WALL_A^2 / 2) Ln^3)      (wall_factor)
+// to g^2 and u^5.  g is a 1e-5 effect on k, but what it leaves out is one-signed, and a one-signed relative error
+// eps of every ratio becomes N eps in the product: the g^2/2 and u^5 terms are 5e-10 each for |r| ~ 2, i.e. 1.6e-4 at
+// N = 2^20, so the steps that feed the product keep them.  The next terms (u^7, g^3) are below 1e-13 there, below
+// 1e-6 for |r| between 1e-2 and 1e2.  Larger |r| only shrinks the influence of k om on the next step; smaller |r| is
+// recorded in lmin (the minimum of Ln over the lane's steps) and the row is handed to the scan kernel.
+// wall_factor_short = 1 + WALL_A Ln^3, for warm-up steps whose error is contracted away before it reaches a product.
+constexpr float WALL_C = 0.69314718055994531f / 176.0f;
+constexpr float WALL_A = 88.0f * WALL_C * WALL_C * WALL_C / 3.0f;
+constexpr float WALL_B = 176.0f * WALL_C * WALL_C * WALL_C * WALL_C * WALL_C / 15.0f;
+constexpr float WALL_LN_MIN = -13.3f;
+__device__ __forceinline__ float wall_factor(float Ln) {
+  const float t = Ln * Ln;
+  const float q = t * Ln;
+  return fmaf(q, fmaf(q, 0.5f * WALL_A * WALL_A, fmaf(t, -WALL_B, WALL_A)), 1.0f);
+}
+__device__ __forceinline__ float wall_factor_short(float Ln) { return fmaf(WALL_A * Ln, Ln * Ln, 1.0f); }
+
+__device__ __forceinline__ float2 ratio_step(float2 al, float k, float2 om, float2 &r, float2 &inv, float &lmin) {
   r = make_float2(fmaf(-k, om.x, al.x), fmaf(-k, om.y, al.y));
   const float n = fmaf(r.x, r.x, r.y * r.y);
   float y = __builtin_amdgcn_rcpf(n);
   y = fmaf(y, fmaf(-n, y, 1.0f), y);
   inv = make_float2(r.x * y, -r.y * y);
-  // clamp factor exp(g(d)), d = -ln|r| = -(ln 2 / 2) log2 |r|^2, |d| limited to 22.  g = -88 (u^3/3 - 2u^5/15),
-  // u = d/88 (|u| <= 1/4: relative error of g below 7e-4, and below 1e-6 for |r| between 1e-2 and 1e2); exp(g) by
-  // its series to g^2 (|g| <= 0.02 for any |r| between 1e-3 and 1e9: 1.4e-6 there, 1e-14 at |r| ~ 2).  The clamp is
-  // a 1e-5 effect on k, so 1e-3 of it is far below float32 resolution.
-  const float u = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(n) * (-LN2_HALF / 88.0f), -0.25f, 0.25f);
-  const float s2 = u * u;
-  const float p = fmaf(s2, 88.0f * 2.0f / 15.0f, -88.0f / 3.0f);
-  const float g = (u * s2) * p;
-  const float wc = fmaf(g, fmaf(g, 0.5f, 1.0f), 1.0f);
+  const float Ln = __builtin_amdgcn_logf(n);
+  lmin = fminf(lmin, Ln);
+  const float wc = wall_factor(Ln);
   return make_float2(inv.x * wc, inv.y * wc);
+}
+// The same step where only om(r) and r are wanted (phi: the product takes s itself, not its reciprocal).
+__device__ __forceinline__ float2 ratio_step_om(float2 al, float k, float2 om, float2 &r, float &lmin) {
+  r = make_float2(fmaf(-k, om.x, al.x), fmaf(-k, om.y, al.y));
+  const float n = fmaf(r.x, r.x, r.y * r.y);
+  float y = __builtin_amdgcn_rcpf(n);
+  y = fmaf(y, fmaf(-n, y, 1.0f), y);
+  const float Ln = __builtin_amdgcn_logf(n);
+  lmin = fminf(lmin, Ln);
+  const float yw = y * wall_factor(Ln);
+  return make_float2(r.x * yw, -r.y * yw);
+}
+// Warm-up form: the short clamp factor and no Newton refinement.  Both leave one-signed errors of 1e-9 .. 1e-8, which
+// the steps after them contract; the last warm-up steps are full steps (ratio_step_om) so that what reaches the lane's
+// own elements, and through them the product, stays below 1e-11 per element.
+__device__ __forceinline__ float2 ratio_step_warm(float2 al, float k, float2 om) {
+  const float2 r = make_float2(fmaf(-k, om.x, al.x), fmaf(-k, om.y, al.y));
+  const float n = fmaf(r.x, r.x, r.y * r.y);
+  const float yw = __builtin_amdgcn_rcpf(n) * wall_factor_short(__builtin_amdgcn_logf(n));
+  return make_float2(r.x * yw, -r.y * yw);
 }
 
 // The same step without the Newton refinement and without the clamp factor (a relative 1e-4 at most for |r| within
@@ -141,7 +225,7 @@ __device__ __forceinline__ bool differs_tight(float2 p, float2 q) {
   return !(fmaf(dx, dx, dy * dy) <= 4.0e-12f * fmaf(q.x, q.x, q.y * q.y));
 }
 
-// Staging of a' and k for elements base - RH .. base + CHUNK + RH - 1 (k: one more), in two halves so that the
+// Staging of a' and k for elements base - RH .. base + RCHUNK + RH - 1 (k: one more), in two halves so that the
 // global loads of the next chunk can be in flight while the current one is computed:
 //   load_ratio   global -> registers (17 rounds of 256 slots cover the RN + 1 = 4129 slots).  Outside the row a = 1,
 //                b = c = 0.  `full` (uniform): every index lies inside the row, no bounds logic.
@@ -160,7 +244,7 @@ __device__ __forceinline__ void load_ratio(const TIn *__restrict__ a, const TIn 
   if (full) {
 #pragma unroll
     for (int j = 0; j < RNJ; ++j) {
-      const int q = min(t + j * T, RN);
+      const int q = min(t + j * RT, RN);
       av[j] = to_f32<TIn>(a0[q]);
       bv[j] = to_f32<TIn>(b0[q]);
       cv[j] = to_f32<TIn>(c0[q]);
@@ -175,7 +259,7 @@ __device__ __forceinline__ void load_ratio(const TIn *__restrict__ a, const TIn 
     const int ca = max(hi_a, lo_a), ck = max(hi_k, lo_k);
 #pragma unroll
     for (int j = 0; j < RNJ; ++j) {
-      const int q = min(t + j * T, RN);
+      const int q = min(t + j * RT, RN);
       const int qa = min(max(q, lo_a), ca);
       const int qk = min(max(q, lo_k), ck);
       const float va = to_f32<TIn>(a0[qa]);
@@ -188,43 +272,69 @@ __device__ __forceinline__ void load_ratio(const TIn *__restrict__ a, const TIn 
   }
 }
 
-__device__ __forceinline__ unsigned commit_ratio(const RowCfg &cfg, float (&av)[RNJ], float (&bv)[RNJ],
-                                                 float (&cv)[RNJ], SharedR &sh) {
+// Padded LDS slot of staged slot q = t + j * RT: q + q / E = (t + t / E) + j * (RT + RT / E), a per-thread base plus a
+// compile-time offset (written out because the compiler does not split the division by itself).
+static_assert(RT % E == 0, "padded slot arithmetic");
+constexpr int RQS = RT + RT / E;
+
+// EXACT: the operator's NaN rules element by element (bk_core.py:256-264), for a chunk in which some value is a NaN;
+// otherwise the clamps alone (v_med3).  The raw input registers are left as loaded.
+template <bool EXACT>
+__device__ __forceinline__ unsigned commit_pass(const RowCfg &cfg, const float (&av)[RNJ], const float (&bv)[RNJ],
+                                                const float (&cv)[RNJ], SharedR &sh) {
   unsigned seen = 0;
   const int t = threadIdx.x;
-  if (!cfg.raw) {
-    float probe = 0.0f;
-#pragma unroll
-    for (int j = 0; j < RNJ; ++j) probe += av[j] + (bv[j] + cv[j]);
-    if (__builtin_expect(!__any(probe != probe), 1)) {
-#pragma unroll
-      for (int j = 0; j < RNJ; ++j) {
-        av[j] = __builtin_amdgcn_fmed3f(av[j], -100.0f, 100.0f);
-        bv[j] = __builtin_amdgcn_fmed3f(bv[j], -10.0f, 10.0f);
-        cv[j] = __builtin_amdgcn_fmed3f(cv[j], -10.0f, 10.0f);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < RNJ; ++j) {
-        float v = clamp_keep_nan(av[j], 100.0f);
-        if (v != v) { v = 0.0f; seen |= 1u; }
-        av[j] = v;
-        float p = clamp_keep_nan(bv[j], 10.0f), qv = clamp_keep_nan(cv[j], 10.0f);
-        if (p != p) { seen |= 2u; if (cfg.fix_bc) p = 1.0f; }
-        if (qv != qv) { seen |= 2u; if (cfg.fix_bc) qv = 1.0f; }
-        bv[j] = p;
-        cv[j] = qv;
-      }
-    }
-  }
+  float2 *__restrict__ al_t = sh.u.in.al_s + (t + t / E);
+  float *__restrict__ k_t = sh.u.in.k_s + (t + t / E);
+  const float xi = -cfg.z.y, xi2 = xi * xi;
+  const bool zfar = xi2 >= 1e-24f;  // uniform: a - z is never near zero, the regularisation needs no special case
 #pragma unroll
   for (int j = 0; j < RNJ; ++j) {
-    const int q = t + j * T;
+    float a = av[j], b = bv[j], c = cv[j];
+    if (!cfg.raw) {
+      if (EXACT) {
+        a = clamp_keep_nan(a, 100.0f);
+        if (a != a) { a = 0.0f; seen |= 1u; }
+        b = clamp_keep_nan(b, 10.0f);
+        c = clamp_keep_nan(c, 10.0f);
+        if (b != b) { seen |= 2u; if (cfg.fix_bc) b = 1.0f; }
+        if (c != c) { seen |= 2u; if (cfg.fix_bc) c = 1.0f; }
+      } else {
+        a = __builtin_amdgcn_fmed3f(a, -100.0f, 100.0f);
+        b = __builtin_amdgcn_fmed3f(b, -10.0f, 10.0f);
+        c = __builtin_amdgcn_fmed3f(c, -10.0f, 10.0f);
+      }
+    }
+    float2 al;
+    if (zfar) {
+      const float xr = a - cfg.z.x;
+      const float f = fmaf(1e-3f, __builtin_amdgcn_rsqf(fmaf(xr, xr, xi2)), 1.0f);
+      al = make_float2(xr * f, xi * f);
+    } else {
+      al = reg_alpha(a, cfg);
+    }
+    const int q = t + j * RT;
     if (j < E || q <= RN) {
-      sh.u.in.k_s[rpad16(q)] = bv[j] * cv[j];
-      if (j < E || q < RN) sh.u.in.al_s[rpad16(q)] = reg_alpha(av[j], cfg);
+      k_t[j * RQS] = b * c;
+      if (j < E || q < RN) al_t[j * RQS] = al;
     }
   }
+  return seen;
+}
+
+__device__ __forceinline__ unsigned commit_ratio(const RowCfg &cfg, const float (&av)[RNJ], const float (&bv)[RNJ],
+                                                 const float (&cv)[RNJ], SharedR &sh) {
+  bool nan = false;  // v_cmp_u tests two values per instruction
+  if (!cfg.raw) {
+#pragma unroll
+    for (int j = 0; j < RNJ; ++j) {
+      nan |= __builtin_isunordered(av[j], bv[j]);
+      if (j & 1) nan |= __builtin_isunordered(cv[j - 1], cv[j]);
+    }
+    nan |= __builtin_isunordered(cv[RNJ - 1], cv[RNJ - 1]);
+  }
+  unsigned seen = commit_pass<false>(cfg, av, bv, cv, sh);
+  if (__builtin_expect(__any(nan), 0)) seen = commit_pass<true>(cfg, av, bv, cv, sh);  // rewrites the wave's slots
   return seen;
 }
 
@@ -239,7 +349,7 @@ __device__ __forceinline__ unsigned commit_ratio(const RowCfg &cfg, float (&av)[
 // SAVE (MODE 0 only, for the analytic backward): also stores r_j and s_j, and writes G_raw (before the final
 // log-magnitude clamp and the clip; 0 outside 1e-18 <= |G_raw| <= 1e18) instead of G.
 template <typename TIn, bool PHI_EXACT, int MODE, bool SAVE = false>
-__global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
+__global__ __launch_bounds__(RT, (MODE == 0 && !SAVE) ? BK_RATIO_WAVES : 2) void bk_ratio_forward_kernel(
     const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
     const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, float2 *__restrict__ G_,
     float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, unsigned flags, float fclamp, int S,
@@ -254,7 +364,7 @@ __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
   const TIn *c = N >= 2 ? c_ + row * ldc : a;
   float2 *G = G_ + row * N;
   float2 *F = F_ ? F_ + row * N : nullptr;
-  const int nch = (int)((N + CHUNK - 1) / CHUNK);
+  const int nch = (int)((N + RCHUNK - 1) / RCHUNK);
   const int ch0 = MODE == 0 ? 0 : sg * seg_ch;
   const int ch1 = MODE == 0 ? nch : min(nch, ch0 + seg_ch);
   float *info = reinterpret_cast<float *>(ws + rowflag_bytes(B) + lane_state_bytes(B, N)) + (row * S + sg) * SEG_INFO;
@@ -267,7 +377,7 @@ __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
-  const int seg = T - 1 - t;  // descending segments over ascending threads: the product runs right -> left
+  const int seg = RT - 1 - t;  // descending segments over ascending threads: the product runs right -> left
   constexpr int KO = PHI_EXACT ? 1 : 0;
   unsigned seen = 0;
   bool bad = false;
@@ -281,59 +391,120 @@ __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
     sh.carry[0] = p0;
   }
 
-  // raw inputs of the chunk about to be processed, loaded one chunk ahead
+  // Raw inputs of the chunk about to be processed.  One workgroup per row without the saving stores fits 3 waves per
+  // SIMD (168 registers) when the loads are issued at the start of the chunk and the CU's other workgroups cover their
+  // latency; the other variants hold the next chunk's inputs in registers during the current chunk's arithmetic
+  // (2 waves per SIMD).
+  constexpr bool PREFETCH = !(MODE == 0 && !SAVE && BK_RATIO_WAVES >= 3) && BK_RATIO_PREFETCH;
   float av[RNJ], bv[RNJ], cv[RNJ];
   auto prefetch = [&](int ch) __attribute__((always_inline)) {
-    // chunks 1 .. nch-3 lie at least a halo away from both ends of the row
-    load_ratio<TIn>(a, b, c, (long)ch * CHUNK, N, ch >= 1 && ch <= nch - 3, av, bv, cv);
+    // `full`: the chunk and its halos (and the one extra k) lie inside the row
+    load_ratio<TIn>(a, b, c, (long)ch * RCHUNK, N, ch >= 1 && (long)(ch + 1) * RCHUNK + RH + 1 <= N, av, bv, cv);
   };
   auto one = [&](auto tail, int ch) __attribute__((always_inline)) {
     constexpr bool TAIL = decltype(tail)::value;
-    const long base = (long)ch * CHUNK;
+    const long base = (long)ch * RCHUNK;
 
+    BK_STAMP(0);
+    if (!PREFETCH) prefetch(ch);  // no software pipelining: the other workgroups of the CU cover the latency
     __syncthreads();  // previous chunk's output tile has been stored
+    BK_STAMP(1);
     seen |= commit_ratio(cfg, av, bv, cv, sh);
-
+    BK_STAMP(2);
     __syncthreads();
-    if (ch > ch0) prefetch(ch - 1);  // in flight during this chunk's arithmetic
+    BK_STAMP(3);
+    if (PREFETCH && ch > ch0) prefetch(ch - 1);  // in flight during this chunk's arithmetic
 
     const int q0 = seg * E + RH;      // staged slot of the lane's first element (a multiple of 16)
     const float2 *al_l = sh.u.in.al_s + rpad16(q0);
     const float *k_l = sh.u.in.k_s + rpad16(q0);
     const long i0 = base + (long)seg * E;
-    float2 ir[E];                     // 1 / r_e
-    float2 sv[E];                     // s_e; later the lane-local part of G_raw
-    // theta runs left -> right, phi right -> left; the two chains are independent and advance in the same loop
-    // iteration so that each wave always has two dependency chains in flight.  Warm-up: theta over the 16 elements
-    // to the left of the lane's own, phi over the 16 to the right.  Past the end of the row om_phi = 0
-    // (phi_{N+1} = 0: the recurrence starts with s_{N-1} = a'_{N-1}).
+    float2 ir[E];                     // 1 / r_e; then (unless SAVE) the lane-local part of G_raw
+    float2 sv[SAVE ? E : 1];          // s_e and the lane-local part of G_raw as arrays of their own: saving variant only
+    float2 lc[SAVE ? E : 1];
+    // Warm-up: theta over the 16 elements to the left of the lane's own, phi over the 16 to the right, the two
+    // independent chains side by side.  Past the end of the row om_phi = 0 (phi_{N+1} = 0: the recurrence starts with
+    // s_{N-1} = a'_{N-1}).
+#if BK_RATIO_EXPERIMENT == 1
+    // development: no chain arithmetic at all (memory and staging floor of the kernel)
+    float2 wt = make_float2(0.f, 0.f), wp = make_float2(0.f, 0.f), r = wt, inv = wt;
+    float lmin = 0.0f;
+    const float2 th_west = wt, ph_west = wp, th_fin = wt;
+    Prod run = prod_one();
+    int le[E / 4];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      ir[j] = al_l[roff(j)];
+      ir[j].x += k_l[roff(j)];
+      le[j >> 2] = 0;
+    }
+    (void)r; (void)inv;
+#else
     float2 wt = make_float2(0.f, 0.f), wp = make_float2(0.f, 0.f), r, inv;
+    float lmin = 0.0f;
 #pragma unroll
     for (int j = 0; j < RH; ++j) {
       const int d = E + RH - 1 - j;
       if (j < RH_COARSE) {
         wt = ratio_step_coarse(al_l[roff(j - RH)], k_l[roff(j - RH)], wt);
         wp = ratio_step_coarse(al_l[roff(d)], k_l[roff(d + KO)], wp);
+      } else if (j < RH - RH_FULL) {
+        wt = ratio_step_warm(al_l[roff(j - RH)], k_l[roff(j - RH)], wt);
+        wp = ratio_step_warm(al_l[roff(d)], k_l[roff(d + KO)], wp);
       } else {
-        wt = ratio_step(al_l[roff(j - RH)], k_l[roff(j - RH)], wt, r, inv);
-        wp = ratio_step(al_l[roff(d)], k_l[roff(d + KO)], wp, r, inv);
+        float lw = 0.0f;  // the warm-up's own small ratios are not the row's
+        wt = ratio_step_om(al_l[roff(j - RH)], k_l[roff(j - RH)], wt, r, lw);
+        wp = ratio_step_om(al_l[roff(d)], k_l[roff(d + KO)], wp, r, lw);
       }
       if (TAIL && i0 + d >= N) wp = make_float2(0.f, 0.f);
+      BK_SCHED_FENCE(j);
     }
     const float2 th_west = wt, ph_west = wp;
+
+    BK_STAMP(4);
+    // theta over the lane's own elements, left -> right: keeps 1 / r_e
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-      wt = ratio_step(al_l[roff(j)], k_l[roff(j)], wt, r, inv);
+      wt = ratio_step(al_l[roff(j)], k_l[roff(j)], wt, r, inv, lmin);
       ir[j] = inv;
-      const int e = E - 1 - j;
-      wp = ratio_step(al_l[roff(e)], k_l[roff(e + KO)], wp, r, inv);
-      if (TAIL && i0 + e >= N) wp = make_float2(0.f, 0.f);
-      sv[e] = r;
+      BK_SCHED_FENCE(j);
     }
-    const float2 th_fin = wt, ph_fin = wp;
-    if (SAVE) {
+    const float2 th_fin = wt;
+
+    BK_STAMP(5);
+    // phi right -> left with the lane-local products folded in: loc_e = (1/r_e) * prod_{e' > e} s_e' / r_e' replaces
+    // 1/r_e in its registers, and the running product picks up s_e / r_e as loc_e * s_e (a second dependency chain
+    // beside the recurrence).  Exponents are shared by groups of 4.
+    Prod run = prod_one();
+    int le[E / 4];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      const int e = E - 1 - j;
+      wp = ratio_step_om(al_l[roff(e)], k_l[roff(e + KO)], wp, r, lmin);
+      if (TAIL && i0 + e >= N) wp = make_float2(0.f, 0.f);
+      const bool valid = !TAIL || i0 + e < N;
+      const float2 loc = cmul(ir[e], run.m);
+      if (valid) run.m = cmul(loc, r);
+      if constexpr (SAVE) {
+        sv[e] = r;
+        lc[e] = loc;
+      } else {
+        ir[e] = loc;
+      }
+      if ((e & 3) == 0) {  // end of a group of 4: record the exponent it was processed under, then renormalise
+        le[e >> 2] = run.e;
+        pnorm(run);
+      }
+      BK_SCHED_FENCE(j);
+    }
+#endif
+    const float2 ph_fin = wp;
+
+    BK_STAMP(6);
+    bad |= !(lmin >= WALL_LN_MIN);  // a ratio below 1e-2 in magnitude: outside the clamp factor's series
+    if constexpr (SAVE) {
       // r and s leave through the output tile (it overlays the staging area: wait until every wave's chains are done)
-      const int n_sv = TAIL ? (int)max(0L, min((long)CHUNK, N - base)) : CHUNK;
+      const int n_sv = TAIL ? (int)max(0L, min((long)RCHUNK, N - base)) : RCHUNK;
       float2 *slot_sv = &sh.u.out_s[pad16(seg * E)];
 #pragma unroll 1
       for (int pass = 0; pass < 2; ++pass) {
@@ -352,27 +523,11 @@ __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
         float2 *__restrict__ dst = (pass == 0 ? save_r_ : save_s_) + row * N + base;
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-          const int idx = t + j * T;
+          const int idx = t + j * RT;
           if (!TAIL || idx < n_sv) dst[idx] = sh.u.out_s[pad16(idx)];
         }
       }
       __syncthreads();
-    }
-
-    // lane-local products, descending: loc_e = (1/r_e) * prod_{e' > e} s_e' / r_e', exponents shared by groups of 4
-    Prod run = prod_one();
-    int le[E / 4];
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-      const int e = E - 1 - j;
-      const bool valid = !TAIL || i0 + e < N;
-      const float2 q1 = cmul(sv[e], ir[e]);  // s_e / r_e
-      sv[e] = cmul(ir[e], run.m);
-      if (valid) run.m = cmul(run.m, q1);
-      if ((e & 3) == 0) {  // end of a group of 4: record the exponent it was processed under, then renormalise
-        le[e >> 2] = run.e;
-        pnorm(run);
-      }
     }
 
     // workgroup exclusive product over ascending threads
@@ -393,10 +548,11 @@ __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
     const float4 nbv = make_float4(dpp_f<DPP_WAVE_SHR1, 0xF>(0.f, th_west.x), dpp_f<DPP_WAVE_SHR1, 0xF>(0.f, th_west.y),
                                    dpp_f<DPP_WAVE_SHR1, 0xF>(0.f, ph_fin.x), dpp_f<DPP_WAVE_SHR1, 0xF>(0.f, ph_fin.y));
     __syncthreads();
+    BK_STAMP(7);
     Prod v = sh.carry[buf];
     Prod fin_in = v;
 #pragma unroll
-    for (int wv = 0; wv < WAVES; ++wv) {
+    for (int wv = 0; wv < RWAVES; ++wv) {
       if (wv == wave) fin_in = v;
       v = pmul(v, sh.tot[buf][wv]);
     }
@@ -412,65 +568,117 @@ __global__ __launch_bounds__(T, BK_RATIO_WAVES) void bk_ratio_forward_kernel(
         bad |= differs_tight(make_float2(nb.x, nb.y), th_fin);
         bad |= differs_tight(ph_west, make_float2(nb.z, nb.w));
       }
-      if (t == T - 1) sh.edge[buf] = make_float4(th_west.x, th_west.y, ph_fin.x, ph_fin.y);
+      if (t == RT - 1) sh.edge[buf] = make_float4(th_west.x, th_west.y, ph_fin.x, ph_fin.y);
       if (MODE == 1) {  // the two ends of the segment are checked against its neighbours by the combine kernel
         if (t == 0 && ch == ch1 - 1) {
           info[4] = th_fin.x; info[5] = th_fin.y; info[6] = ph_west.x; info[7] = ph_west.y;
         }
-        if (t == T - 1 && ch == ch0) {
+        if (t == RT - 1 && ch == ch0) {
           info[8] = th_west.x; info[9] = th_west.y; info[10] = ph_fin.x; info[11] = ph_fin.y;
         }
       }
     }
     if (MODE == 1) return;  // only the product was wanted
+    // (every wave finished reading the staged inputs before the barrier above: the tile may overwrite them)
 
-    __syncthreads();  // staged inputs are dead: the tile may overwrite them
-
-    // epilogue (bk_core.py:190-208) into the output tile
+    // epilogue (bk_core.py:190-208) into the output tile.  Lq = log2 |G_raw|^2; the final soft clamp multiplies by
+    // exp(g(L)), L = ln|G_raw| = (ln2 / 2) Lq, g(L) = 88 tanh(L/88) - L = -88 (u^3/3 - 2u^5/15 + 17u^7/315 ...),
+    // u = L/88 = WALL_C Lq.  In base 2: log2(e) g = Lq^3 (EPI_A + EPI_B Lq^2); the dropped u^7 term is below 2e-6 of
+    // g for |L| <= 10.  Elements with L outside [-8, 3.9] (the clip |G| > 50 is L > 3.9146; tiny |G|; anything not a
+    // number) take the exact path of the scan kernel's epilogue.
+    constexpr float EPI_A = -LOG2E * 88.0f * WALL_C * WALL_C * WALL_C / 3.0f;
+    constexpr float EPI_B = LOG2E * 88.0f * 2.0f * WALL_C * WALL_C * WALL_C * WALL_C * WALL_C / 15.0f;
+    constexpr float LQ_LO = -8.0f / LN2_HALF, LQ_HI = 3.9f / LN2_HALF;
+    BK_STAMP(8);
     float2 *slot = &sh.u.out_s[pad16(seg * E)];
+    bool rare = false;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const float2 P = cmul(sv[e], Fin.m);
+      float2 P;
+      if constexpr (SAVE) P = cmul(lc[e], Fin.m);
+      else P = cmul(ir[e], Fin.m);
       const int Ee = Fin.e + le[e >> 2];
+      const float Ef = (float)Ee;
       const float n = fmaf(P.x, P.x, P.y * P.y);
-      const float L = LN2_HALF * fmaf(2.0f, (float)Ee, __builtin_amdgcn_logf(n));  // ln |G_raw|
+      const float Lq = fmaf(2.0f, Ef, __builtin_amdgcn_logf(n));
       float2 gv;
       if (SAVE) {
-        gv = (fabsf(L) <= 41.4f) ? make_float2(ldexpf(P.x, Ee), ldexpf(P.y, Ee)) : make_float2(0.f, 0.f);
+        gv = (fabsf(LN2_HALF * Lq) <= 41.4f) ? make_float2(ldexpf(P.x, Ee), ldexpf(P.y, Ee)) : make_float2(0.f, 0.f);
       } else {
-        const float sc = ldexpf(__builtin_amdgcn_exp2f(wall_exponent(L) * LOG2E), Ee);
+        const float t2 = Lq * Lq;
+        const float sc = __builtin_amdgcn_exp2f(fmaf(t2 * Lq, fmaf(t2, EPI_B, EPI_A), Ef));
         gv = make_float2(P.x * sc, P.y * sc);
-        const float m2 = fmaf(gv.x, gv.x, gv.y * gv.y);
-        if (__builtin_expect(!(m2 <= 2500.0f), 0)) {
-          const float u = 50.0f * __builtin_amdgcn_rsqf(n);
-          gv = (L > 3.9f && L <= 3.0e38f && u <= 3.0e38f) ? make_float2(P.x * u, P.y * u) : make_float2(0.f, 0.f);
-        }
+        rare |= !(fabsf(Lq - 0.5f * (LQ_HI + LQ_LO)) <= 0.5f * (LQ_HI - LQ_LO));
       }
       slot[e] = gv;
     }
+    if (!SAVE && __builtin_expect(__any(rare), 0)) {
+      // some element of this wave is outside the short series' range: the lanes redo their elements exactly
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        float2 P;
+        if constexpr (SAVE) P = cmul(lc[e], Fin.m);
+        else P = cmul(ir[e], Fin.m);
+        const int Ee = Fin.e + le[e >> 2];
+        const float n = fmaf(P.x, P.x, P.y * P.y);
+        const float L = LN2_HALF * fmaf(2.0f, (float)Ee, __builtin_amdgcn_logf(n));  // ln |G_raw|
+        const float sx = ldexpf(__builtin_amdgcn_exp2f(wall_exponent(L) * LOG2E), Ee);
+        float2 gv = make_float2(P.x * sx, P.y * sx);
+        const float m2 = fmaf(gv.x, gv.x, gv.y * gv.y);
+        if (!(m2 <= 2500.0f)) {
+          const float u = 50.0f * __builtin_amdgcn_rsqf(n);
+          gv = (L > 3.9f && L <= 3.0e38f && u <= 3.0e38f) ? make_float2(P.x * u, P.y * u) : make_float2(0.f, 0.f);
+        }
+        slot[e] = fix_tiny(gv);
+      }
+    }
+    BK_STAMP(9);
     __syncthreads();
+    BK_STAMP(10);
     float2 *__restrict__ Gc = G + base;
     float2 *__restrict__ Fc = F ? F + base : nullptr;
-    const int n_here = TAIL ? (int)max(0L, min((long)CHUNK, N - base)) : CHUNK;
+    const int n_here = TAIL ? (int)max(0L, min((long)RCHUNK, N - base)) : RCHUNK;
+    const bool clampf = cfg.fclamp <= 3.0e38f;  // uniform
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-      const int idx = t + j * T;
+      const int idx = t + j * RT;
       if (!TAIL || idx < n_here) {
-        const float2 gv = SAVE ? sh.u.out_s[pad16(idx)] : fix_tiny(sh.u.out_s[pad16(idx)]);
+        const float2 gv = sh.u.out_s[(t + (t >> 4)) + j * (RT + RT / 16)];  // pad16(idx)
         __builtin_nontemporal_store(gv.x, &Gc[idx].x);
         __builtin_nontemporal_store(gv.y, &Gc[idx].y);
         if (Fc) {
-          __builtin_nontemporal_store(__builtin_amdgcn_fmed3f(gv.x, -cfg.fclamp, cfg.fclamp), &Fc[idx].x);
-          __builtin_nontemporal_store(__builtin_amdgcn_fmed3f(gv.y, -cfg.fclamp, cfg.fclamp), &Fc[idx].y);
+          if (clampf) {
+            __builtin_nontemporal_store(__builtin_amdgcn_fmed3f(gv.x, -cfg.fclamp, cfg.fclamp), &Fc[idx].x);
+            __builtin_nontemporal_store(__builtin_amdgcn_fmed3f(gv.y, -cfg.fclamp, cfg.fclamp), &Fc[idx].y);
+          } else {
+            __builtin_nontemporal_store(gv.x, &Fc[idx].x);
+            __builtin_nontemporal_store(gv.y, &Fc[idx].y);
+          }
         }
       }
     }
+    BK_STAMP(11);
   };
-  // chunk kinds: the last two (anything at or past the end of the row within reach of a halo), then the others
-  prefetch(ch1 - 1);
+#if BK_RATIO_STAMPS
+  if (threadIdx.x == 0)
+    reinterpret_cast<unsigned long long *>(ws + rowflag_bytes(B))[(row * nch) * 16 + 14] = wall_clock64();
+  if (threadIdx.x == 0)
+    reinterpret_cast<unsigned long long *>(ws + rowflag_bytes(B))[(row * nch) * 16 + 13] =
+        ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | (unsigned)__builtin_amdgcn_s_getreg(0xF804);
+#endif
+#if BK_RATIO_STAGGER > 0
+  // development: start the workgroups at different phases of the chunk period
+  for (int i = (int)((blockIdx.x * 2654435761u) >> 28); i > 0; --i) __builtin_amdgcn_s_sleep(BK_RATIO_STAGGER);
+#endif
+  // chunk kinds: those within reach of a halo of the end of the row (the last one or two), then the others
+  if (PREFETCH) prefetch(ch1 - 1);
   int ch = ch1 - 1;
-  for (; ch >= ch0 && ch >= nch - 2; --ch) one(BoolC<true>{}, ch);
+  for (; ch >= ch0 && (long)(ch + 1) * RCHUNK + RH + 1 > N; --ch) one(BoolC<true>{}, ch);
   for (; ch >= ch0; --ch) one(BoolC<false>{}, ch);
+#if BK_RATIO_STAMPS
+  if (threadIdx.x == 0)
+    reinterpret_cast<unsigned long long *>(ws + rowflag_bytes(B))[(row * nch) * 16 + 15] = wall_clock64();
+#endif
   const int any_bad = __syncthreads_or(bad ? 1 : 0);
   if (t == 0) {
     if (MODE == 0) {
@@ -560,7 +768,7 @@ void ratio_launch(int mode, int save, const void *a, long lda, const void *b, lo
                   void *state, int call_id, unsigned flags, float fclamp, int S, int seg_ch, float *save_r,
                   float *save_s, hipStream_t stream) {
 #define BK_RATIO(MODE, SAVE, GRID)                                                                                   \
-  hipLaunchKernelGGL((bk_ratio_forward_kernel<TIn, PHI_EXACT, MODE, SAVE>), dim3((unsigned)(GRID)), dim3(T), 0,      \
+  hipLaunchKernelGGL((bk_ratio_forward_kernel<TIn, PHI_EXACT, MODE, SAVE>), dim3((unsigned)(GRID)), dim3(RT), 0,      \
                      stream, (const TIn *)a, lda, (const TIn *)b, ldb, (const TIn *)c, ldc, z_dev, z_re, z_im, B, N, \
                      (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id, flags, fclamp, S, seg_ch,   \
                      (float2 *)save_r, (float2 *)save_s)
@@ -600,6 +808,8 @@ extern "C" void bkcore_internal_ratio_forward(int in_dtype, int phi_exact, int m
   }
 #undef BK_DISPATCH
 }
+
+extern "C" int bkcore_internal_ratio_chunk(void) { return RCHUNK; }
 
 extern "C" void bkcore_internal_ratio_combine(int64_t B, int64_t N, void *ws, void *state, int call_id, int S,
                                               void *stream) {

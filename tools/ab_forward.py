@@ -1,0 +1,61 @@
+"""Development A/B: load a given build of the library, check the headline forward against the C oracle on a row
+subset, count rows handed to the fallback, time forward and forward+backward.
+usage: ab_forward.py [--lib path/to/libbkcore.so] [--tag name]"""
+import argparse, os, sys, json
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "project-resnet-bk-an-o-n-language-model-architecture_amd"))
+ap = argparse.ArgumentParser()
+ap.add_argument("--lib", default=None)
+ap.add_argument("--tag", default="lib")
+ap.add_argument("--iters", type=int, default=100)
+args = ap.parse_args()
+from bkcore import _lib
+if args.lib:
+    _lib.LIB_PATH = os.path.abspath(args.lib)
+import bkcore
+from bkcore import bk_core
+from oracle import bk_oracle_c as C
+
+def timed(fn, iters):
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for e0, e1 in ev:
+        e0.record(); fn(); e1.record()
+    torch.cuda.synchronize()
+    ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    return ts[len(ts) // 2], ts[0]
+
+out = {"tag": args.tag}
+B, N = 1024, 32768
+g = torch.Generator(device="cuda").manual_seed(1234)
+a = -2.0 + 0.5 * torch.randn(B, N, device="cuda", generator=g)
+b = torch.ones(B, N - 1, device="cuda")
+z = torch.tensor(1j, dtype=torch.complex64, device="cuda")
+gf = torch.randn(B, N, 2, device="cuda", generator=g)
+bk_core._DEBUG["keep_ws"] = True
+G = bkcore.bk_forward(a, b, b, z)[1]
+torch.cuda.synchronize()
+out["rows_recomputed"] = bk_core.rows_recomputed()
+rows = [0, 1, 511, 1023]
+ref = C.forward_f32(a[rows].cpu().numpy(), b[rows].cpu().numpy(), b[rows].cpu().numpy(), 1j)[1]
+out["err_headline"] = float(np.max(np.abs(G[rows].cpu().numpy() - ref) / np.abs(ref)))
+# position-varying off-diagonals, general z
+g2 = torch.Generator().manual_seed(7)
+a2 = -2.0 + 0.5 * torch.randn(64, N, generator=g2)
+b2 = 1.0 + 0.1 * torch.randn(64, N - 1, generator=g2)
+c2 = 1.0 + 0.1 * torch.randn(64, N - 1, generator=g2)
+G2 = bkcore.vmapped_get_diag(a2.cuda(), b2.cuda(), c2.cuda(), 0.3 + 0.9j)
+torch.cuda.synchronize()
+out["rows_recomputed_var"] = bk_core.rows_recomputed()
+rows = [0, 31, 63]
+ref2 = C.get_diag(a2[rows].numpy(), b2[rows].numpy(), c2[rows].numpy(), 0.3 + 0.9j)
+out["err_varying"] = float(np.max(np.abs(G2[rows].cpu().numpy() - ref2) / np.abs(ref2)))
+bk_core._DEBUG["keep_ws"] = False
+f_med, f_min = timed(lambda: bkcore.bk_forward(a, b, b, z), args.iters)
+fb_med, fb_min = timed(lambda: bkcore.bk_backward_reference(bkcore.bk_forward(a, b, b, z)[1], gf, None, 0.5), args.iters)
+out.update(fwd_ms_med=round(f_med, 4), fwd_ms_min=round(f_min, 4), fwdbwd_ms_med=round(fb_med, 4), fwdbwd_ms_min=round(fb_min, 4),
+           fwd_frac=round(28 * B * N / (f_med * 1e-3) / 8e12, 4), fwdbwd_frac=round(48 * B * N / (fb_med * 1e-3) / 8e12, 4))
+print(json.dumps(out), flush=True)
