@@ -8,9 +8,13 @@ batch of B = 1024 rows of N = 32768 (BASELINE.json configs[1]) held in HBM.  Wit
 torch.distributed.run, one rank per GPU) every rank processes its own B rows -- the operator shards by
 batch row and needs no collective -- and the reported value is the whole-job rate (weak scaling).
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the forward scan) by its algorithmic
-bytes (28 B per diag-element: read a, b, c; write G and features) over its average launch time measured
-with stream events; `cpu_baseline` times the CPU oracle (C port of the reference algorithm, OpenMP) on a
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (torch.distributed.run on
+127.0.0.1, a child process, before this process touches a GPU); launched under torch.distributed.run it is one rank.
+`--total-rows R` shards R rows over the ranks instead (strong scaling, BASELINE.json configs[3] with R = 8192).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the forward) by its algorithmic bytes (20 B per
+diag-element: read a, b, c; write G, whose float32 view is the features output -- 28 B when the features are
+written as a second tensor, reported beside it) over its average launch time measured with stream events; `cpu_baseline` times the CPU oracle (C port of the reference algorithm, OpenMP) on a
 bounded sample of the same workload on this box's host cores.
 """
 import argparse
@@ -25,14 +29,29 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-
-FWD_BYTES = 28.0   # per diag-element: a,b,c reads (3x4) + G write (8) + features write (8)
+FWD_BYTES = 20.0   # per diag-element: a,b,c reads (3x4) + G write (8); the features are the float32 view of G
+FWD_BYTES_TWO = 28.0  # the same with the features written as a second tensor (SHARE_FEATURES_STORAGE = False)
 BWD_BYTES = 20.0   # per diag-element: G read (8) + grad_features read (8) + grad_he_diag write (4)
 HBM_PEAK = 8.0e12  # MI355X HBM3E nominal bytes/s
 
 
+def launch_ranks(argv, n):
+    """Start n ranks of this script under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) as a
+    child process and return its exit code.  Called before anything in this process has touched a GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def make_inputs(B, N, device, seed):
+    import torch
     g = torch.Generator(device=device).manual_seed(seed)
     a = (-2.0 + 0.5 * torch.randn(B, N, generator=g, device=device)).requires_grad_(True)
     b = torch.ones(B, N - 1, device=device)
@@ -71,6 +90,7 @@ def cpu_baseline(N, budget_s=12.0):
 def cpu_baseline_torch_loop(N_sub=16384, B=64):
     """Restatement of the reference's own cost model (Python loop over N of batched complex128 torch ops),
     forward only, on an N-subsample; the reference path costs ~constant time per sequence position."""
+    import torch
     from oracle import bk_oracle_torch as O
     g = torch.Generator().manual_seed(0)
     a = -2.0 + 0.5 * torch.randn(B, N_sub, generator=g)
@@ -82,40 +102,133 @@ def cpu_baseline_torch_loop(N_sub=16384, B=64):
             "sample": f"torch complex128 loop (reference cost model), fwd, B={B} x N={N_sub} in {t:.2f} s"}
 
 
+def cpu_step_stub(B, N, seed):
+    """--device cpu: the step of the launcher test (tests/test_bench_launcher.py) -- the CPU oracle on a small
+    shape, so that the N-rank plumbing (spawn, rendezvous, barrier, MAX over ranks, one JSON line) runs without a GPU.
+    Never a measured product path."""
+    import numpy as np
+    from oracle import bk_oracle_c as C
+    rng = np.random.default_rng(seed)
+    a = (-2.0 + 0.5 * rng.standard_normal((B, N))).astype(np.float32)
+    b = np.ones((B, N - 1), np.float32)
+    gf = rng.standard_normal((B, N, 2)).astype(np.float32)
+
+    def step():
+        _, G = C.forward_f32(a, b, b, 1j)
+        C.backward_ref(G, gf, None, 0.5)
+    return step
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=1024, help="rows per GPU")
+    ap.add_argument("--batch", type=int, default=1024, help="rows per GPU (weak scaling)")
+    ap.add_argument("--total-rows", type=int, default=0,
+                    help="rows of the whole job, sharded over the ranks (strong scaling; configs[3]: 8192)")
     ap.add_argument("--seq", type=int, default=32768)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--device", choices=("cuda", "cpu"), default="cuda",
+                    help="cpu: launcher test only (gloo, CPU oracle as the step)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(sys.argv[1:], args.gpus))   # nothing GPU-related has run in this process
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    on_gpu = args.device == "cuda"
+    dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(device)
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
+    N = args.seq
+    if args.total_rows:
+        if args.total_rows % world:
+            raise SystemExit("--total-rows must be a multiple of the number of ranks")
+        B = args.total_rows // world
+        scaling = "strong"
+    else:
+        B = args.batch
+        scaling = "weak"
 
-    import bkcore
-    from bkcore import BKCoreFunction
-    B, N = args.batch, args.seq
-    a, b, c, z, gfeat = make_inputs(B, N, device, 1234 + rank)
+    if on_gpu:
+        device = torch.device("cuda", local_rank if world > 1 else 0)
+        torch.cuda.set_device(device)
+        import bkcore
+        from bkcore import BKCoreFunction
+        a, b, c, z, gfeat = make_inputs(B, N, device, 1234 + rank)
 
-    def step():
-        a.grad = None
-        feats, G = BKCoreFunction.apply(a, b, c, z)
-        torch.autograd.backward((feats,), (gfeat,))
+        def step():
+            a.grad = None
+            feats, G = BKCoreFunction.apply(a, b, c, z)
+            torch.autograd.backward((feats,), (gfeat,))
+
+        def sync():
+            torch.cuda.synchronize()
+    else:
+        device = torch.device("cpu")
+        step = cpu_step_stub(B, N, 1234 + rank)
+
+        def sync():
+            pass
 
     def barrier():
         if world > 1:
             dist.barrier()
+        sync()
+
+    # per-kernel launch durations with stream events (same stream the kernels are launched on)
+    def timed(fn, reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
         torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    # per-iteration stream events after warm-ups: median and minimum (the protocol of the reference's own benchmark,
+    # scripts/benchmark_bk_triton.py:101-119, with events in place of host timers)
+    def per_iter(fn, iters=100, warm=10):
+        for _ in range(warm):
+            fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for e0, e1 in ev:
+            e0.record()
+            fn()
+            e1.record()
+        torch.cuda.synchronize()
+        ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+        return ts[len(ts) // 2], ts[0]
+
+    # Kernel-level measurements first (they also bring the device to its working clocks), the timed steps after them.
+    t_fwd = t_bwd = None
+    extra = {}
+    if on_gpu:
+        reps = max(5, args.steps)
+        ad = a.detach()
+        with torch.no_grad():
+            share = BKCoreFunction.SHARE_FEATURES_STORAGE   # time the forward exactly as the step runs it
+            G = bkcore.bk_forward(ad, b, c, z)[1]
+            t_fwd = timed(lambda: bkcore.bk_forward(ad, b, c, z, share_storage=share), reps)
+            t_fwd2 = timed(lambda: bkcore.bk_forward(ad, b, c, z, share_storage=False), reps)
+            t_bwd = timed(lambda: bkcore.bk_backward_reference(G, gfeat, None, 0.5), reps)
+            del G
+        if rank == 0 and world == 1 and not args.no_secondary:
+            extra = secondary_measurements(torch, bkcore, device, B, N, ad, b, c, z, gfeat, timed, per_iter, reps)
 
     for _ in range(args.warmup):
         step()
@@ -130,38 +243,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # per-kernel launch durations with stream events (same stream the kernels are launched on)
-    def timed(fn, reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        fn()
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e-3 / reps
-
-    reps = max(5, args.steps)
-    ad = a.detach()
-    with torch.no_grad():
-        G = bkcore.bk_forward(ad, b, c, z)[1]
-        t_fwd = timed(lambda: bkcore.bk_forward(ad, b, c, z), reps)
-        t_bwd = timed(lambda: bkcore.bk_backward_reference(G, gfeat, None, 0.5), reps)
-
     if rank == 0:
-        # HBM traffic of the dominant kernel from the last committed PMC run (profiles/), if it was this workload
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-            if tj.get("rows") == B and tj.get("seq_len") == N:
-                traffic = tj["bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
         elems = B * N
         ms = dt / args.steps * 1e3
         value = world * elems / (dt / args.steps)
-        fwd_bw = FWD_BYTES * elems / t_fwd
         out = {
             "metric": "bk_core_fwd_bwd_diag_elems_per_sec",
             "value": value,
@@ -171,82 +256,119 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"BK-Core fwd+bwd B={B} N={N} complex64 per GPU (BASELINE.json configs[1]); "
+            "data": "synthetic" if on_gpu else "synthetic (cpu stub of the step: launcher test only)",
+            "config": {"workload": f"BK-Core fwd+bwd B={B} N={N} complex64 per GPU (BASELINE.json "
+                                   f"{'configs[3], rows sharded' if args.total_rows else 'configs[1]'}); "
                                    "he_diag=-2+0.5*randn, h0_super=h0_sub=1, z=1j; reference-mode backward",
                        "rows_per_gpu": B, "seq_len": N, "sharding": f"batch rows x{world}, no collective"},
-            "roofline": {"bound": "hbm", "achieved": fwd_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": fwd_bw / HBM_PEAK, "traffic": traffic,
-                         "kernel": "bk_ratio_forward_kernel", "bytes_per_elem": FWD_BYTES, "launch_ms": t_fwd * 1e3,
-                         "launch_ms_covers": "one forward call = this kernel + the (empty) second launch, ~5 us"},
-            "fwd_ms": t_fwd * 1e3,
-            "bwd_ms": t_bwd * 1e3,
-            "bwd_GBps": BWD_BYTES * elems / t_bwd / 1e9,
-            "hbm_frac_fwd_bwd": (FWD_BYTES + BWD_BYTES) * elems / (t_fwd + t_bwd) / HBM_PEAK,
         }
-        if world == 1:
-            # what a plain device-to-device copy of the same volume reaches on this box (read + write bytes / time)
-            with torch.no_grad():
-                src = torch.empty(B, N, 2, device=device)
-                dst = torch.empty_like(src)
-                t_copy = timed(lambda: dst.copy_(src), reps)
-                out["roofline"]["copy_ceiling_GBps"] = 2 * src.numel() * 4 / t_copy / 1e9
-                del src, dst
-            # secondary measurements (not part of `value`): analytic-mode backward at the same size, and the
-            # long-context configuration BASELINE.json configs[2] (B=16, N=2^20: several workgroups per row)
-            with torch.no_grad():
-                t_ana = timed(lambda: bkcore.bk_backward_analytic(ad, b, c, z, gfeat, None), 5)
-                a3, b3, c3, z3, g3 = make_inputs(16, 1 << 20, device, 99)
-                a3 = a3.detach()
-                G3 = bkcore.bk_forward(a3, b3, c3, z3)[1]
-                t3f = timed(lambda: bkcore.bk_forward(a3, b3, c3, z3), reps)
-                t3b = timed(lambda: bkcore.bk_backward_reference(G3, g3, None, 0.5), reps)
-            # per-iteration stream events over 100 iterations after 10 warm-ups: median and minimum of forward+backward
-            # and of the forward alone (the protocol of the reference's own benchmark, scripts/benchmark_bk_triton.py:101-119)
-            def per_iter(fn, iters=100, warm=10):
-                for _ in range(warm):
-                    fn()
-                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-                for e0, e1 in ev:
-                    e0.record()
-                    fn()
-                    e1.record()
-                torch.cuda.synchronize()
-                ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
-                return ts[len(ts) // 2], ts[0]
-            with torch.no_grad():
-                fb_med, fb_min = per_iter(lambda: bkcore.bk_backward_reference(
-                    bkcore.bk_forward(ad, b, c, z)[1], gfeat, None, 0.5))
-                f_med, f_min = per_iter(lambda: bkcore.bk_forward(ad, b, c, z))
-            out["events_100_iters"] = {"fwd_bwd_ms_median": fb_med, "fwd_bwd_ms_min": fb_min,
-                                       "fwd_ms_median": f_med, "fwd_ms_min": f_min}
-            # the layer's chain around the operator (tanh saturation + bfloat16 cast in front, clamp behind, and the
-            # whole backward chain), two library launches each way, at the same size
-            h0 = torch.full((1, N), -2.0, device=device)
-            vpre = torch.randn(B, N, device=device)
-
-            def layer_chain():
-                vv = vpre.detach().requires_grad_(True)
-                ff, _ = bkcore.FusedBKLayerFunction.apply(vv, h0, b[:1], c[:1], z, 5.0, 5.0)
-                torch.autograd.backward((ff,), (gfeat,))
-            t_chain = timed(layer_chain, 10)
-            del h0, vpre
-            out["secondary"] = {
-                "layer_chain_fused_fwd_bwd_ms": t_chain * 1e3,
-                "analytic_backward_ms": t_ana * 1e3,
-                "analytic_backward_note": "grad for he_diag, h0_super, h0_sub; re-runs the forward inside",
-                "long_context_B16_N1048576": {"fwd_ms": t3f * 1e3, "bwd_ms": t3b * 1e3,
-                                              "diag_elems_per_sec": 16 * (1 << 20) / (t3f + t3b)},
-            }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(N)
-            out["cpu_baseline_reference_cost_model"] = cpu_baseline_torch_loop()
+        if on_gpu:
+            # HBM traffic of the dominant kernel from the last committed PMC run (profiles/), if it was this workload
+            traffic = None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+                if tj.get("rows") == B and tj.get("seq_len") == N:
+                    traffic = tj["bytes_per_launch"]
+            except (OSError, ValueError, KeyError):
+                pass
+            fbytes = FWD_BYTES if BKCoreFunction.SHARE_FEATURES_STORAGE else FWD_BYTES_TWO
+            fwd_bw = fbytes * elems / t_fwd
+            out["roofline"] = {"bound": "hbm", "achieved": fwd_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                               "frac": fwd_bw / HBM_PEAK, "traffic": traffic,
+                               "kernel": "bk_ratio_forward_kernel", "bytes_per_elem": fbytes,
+                               "launch_ms": t_fwd * 1e3,
+                               "launch_ms_covers": "one forward call = this kernel + the (empty) second launch, ~3 us"}
+            out["fwd_ms"] = t_fwd * 1e3
+            out["bwd_ms"] = t_bwd * 1e3
+            out["bwd_GBps"] = BWD_BYTES * elems / t_bwd / 1e9
+            out["hbm_frac_fwd_bwd"] = (fbytes + BWD_BYTES) * elems / (t_fwd + t_bwd) / HBM_PEAK
+            out["hbm_frac_step"] = (fbytes + BWD_BYTES) * elems / (dt / args.steps) / HBM_PEAK
+            out["fwd_two_outputs"] = {"ms": t_fwd2 * 1e3, "bytes_per_elem": FWD_BYTES_TWO,
+                                      "frac": FWD_BYTES_TWO * elems / t_fwd2 / HBM_PEAK,
+                                      "hbm_frac_fwd_bwd": (FWD_BYTES_TWO + BWD_BYTES) * elems / (t_fwd2 + t_bwd) / HBM_PEAK}
+            out["step_overhead_ms"] = ms - (t_fwd + t_bwd) * 1e3   # launch gaps + host time not hidden behind the GPU
+            if "copy_ceiling_GBps" in extra:
+                out["roofline"]["copy_ceiling_GBps"] = extra.pop("copy_ceiling_GBps")
+            out.update(extra)
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(N)
+                out["cpu_baseline_reference_cost_model"] = cpu_baseline_torch_loop()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def secondary_measurements(torch, bkcore, device, B, N, ad, b, c, z, gfeat, timed, per_iter, reps):
+    """Rank 0, one GPU: copy ceiling, event statistics, the other configurations and callers (not part of `value`)."""
+    out = {}
+    with torch.no_grad():
+        # what a plain device-to-device copy of the same volume reaches on this box (read + write bytes / time)
+        src = torch.empty(B, N, 2, device=device)
+        dst = torch.empty_like(src)
+        t_copy = timed(lambda: dst.copy_(src), reps)
+        out["copy_ceiling_GBps"] = 2 * src.numel() * 4 / t_copy / 1e9
+        del src, dst
+        share = bkcore.BKCoreFunction.SHARE_FEATURES_STORAGE
+        fb_med, fb_min = per_iter(lambda: bkcore.bk_backward_reference(
+            bkcore.bk_forward(ad, b, c, z, share_storage=share)[1], gfeat, None, 0.5))
+        f_med, f_min = per_iter(lambda: bkcore.bk_forward(ad, b, c, z, share_storage=share))
+        out["events_100_iters"] = {"fwd_bwd_ms_median": fb_med, "fwd_bwd_ms_min": fb_min,
+                                   "fwd_ms_median": f_med, "fwd_ms_min": f_min}
+        # analytic-mode backward at the same size, and the long-context configuration BASELINE.json configs[2]
+        # (B=16, N=2^20: several workgroups per row)
+        t_ana = timed(lambda: bkcore.bk_backward_analytic(ad, b, c, z, gfeat, None), 5)
+        a3, b3, c3, z3, g3 = make_inputs(16, 1 << 20, device, 99)
+        a3 = a3.detach()
+        G3 = bkcore.bk_forward(a3, b3, c3, z3)[1]
+        t3f = timed(lambda: bkcore.bk_forward(a3, b3, c3, z3), reps)
+        t3b = timed(lambda: bkcore.bk_backward_reference(G3, g3, None, 0.5), reps)
+        del a3, b3, c3, g3, G3
+        # the reference's own published protocol (scripts/benchmark_bk_triton.py:66-70,101-119): B=16, N=4096, randn
+        # a, b, c, z = 0.1+0.1j, forward only, 10 warm-ups + 100 calls each bracketed by a device synchronisation
+        gp = torch.Generator(device=device).manual_seed(0)
+        ap_, bp_, cp_ = (torch.randn(16, n_, generator=gp, device=device) for n_ in (4096, 4095, 4095))
+        zp = torch.tensor(0.1 + 0.1j, dtype=torch.complex64, device=device)
+        for _ in range(10):
+            bkcore.BKCoreFunction.apply(ap_, bp_, cp_, zp, False)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(100):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            Gp = bkcore.BKCoreFunction.apply(ap_, bp_, cp_, zp, False)[1]
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        mean_ms = sum(ts) / len(ts) * 1e3
+        mag = Gp.abs()
+        out["published_protocol"] = {
+            "shape": "B=16 N=4096 randn a,b,c z=0.1+0.1j forward only, host timer + synchronize per call",
+            "mean_ms": mean_ms, "min_ms": min(ts) * 1e3, "diag_elems_per_sec": 16 * 4096 / (mean_ms * 1e-3),
+            "reference_rtx3080_triton_ms": 2.73, "reference_rtx3080_torch_ms": 544.22,
+            "finite_frac": float(torch.isfinite(torch.view_as_real(Gp)).all(-1).float().mean()),
+            "clip_frac": float((mag > 49.99).float().mean()), "zero_frac": float((mag == 0).float().mean())}
+        del ap_, bp_, cp_, Gp
+    # the layer's chain around the operator (tanh saturation + bfloat16 cast in front, clamp behind, and the
+    # whole backward chain), two library launches each way, at the same size
+    h0 = torch.full((1, N), -2.0, device=device)
+    vpre = torch.randn(B, N, device=device)
+
+    def layer_chain():
+        vv = vpre.detach().requires_grad_(True)
+        ff, _ = bkcore.FusedBKLayerFunction.apply(vv, h0, b[:1], c[:1], z, 5.0, 5.0)
+        torch.autograd.backward((ff,), (gfeat,))
+    t_chain = timed(layer_chain, 10)
+    del h0, vpre
+    out["secondary"] = {
+        "layer_chain_fused_fwd_bwd_ms": t_chain * 1e3,
+        "analytic_backward_ms": t_ana * 1e3,
+        "analytic_backward_note": "grad for he_diag, h0_super, h0_sub",
+        "long_context_B16_N1048576": {"fwd_ms": t3f * 1e3, "bwd_ms": t3b * 1e3,
+                                      "diag_elems_per_sec": 16 * (1 << 20) / (t3f + t3b)},
+    }
+    return out
 
 
 if __name__ == "__main__":

@@ -28,6 +28,8 @@ logger = logging.getLogger(__name__)
 _DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16, torch.float64: _lib.F64}
 _DEBUG = {"keep_ws": False, "last_ws": None, "last_B": 0, "scan_path": False}  # diagnostics: see rows_recomputed()
 _state = {}  # (device index, stream handle) -> persistent int32 state block for the NaN-sanitiser corner
+_ws = {}     # (device index, stream handle) -> workspace tensor, grown on demand and reused by every call on the stream
+_ws_bytes = {}  # (B, N) -> bkcore_workspace_bytes(B, N)
 
 
 def _state_block(device: torch.device, stream: int) -> torch.Tensor:
@@ -37,6 +39,42 @@ def _state_block(device: torch.device, stream: int) -> torch.Tensor:
         blk = torch.zeros(_lib.STATE_BYTES // 4, dtype=torch.int32, device=device)
         _state[key] = blk
     return blk
+
+
+def _workspace(L, device: torch.device, stream: int, B: int, N: int):
+    """(tensor, bytes needed).  Calls on one stream execute in order, so one buffer per (device, stream) serves them
+    all; it only ever grows.  The size query is cached per shape."""
+    need = _ws_bytes.get((B, N))
+    if need is None:
+        need = int(L.bkcore_workspace_bytes(B, N))
+        _ws_bytes[(B, N)] = need
+    key = (device.index, stream)
+    ws = _ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=device)
+        _ws[key] = ws
+    return ws, need
+
+
+class _on_device:
+    """`with _on_device(dev):` makes dev current for the launch; costs nothing when it already is (the usual case),
+    unlike torch.cuda.device."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, dev: torch.device):
+        self.idx = dev.index
+        self.prev = -1
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+        return False
 
 
 def _rows(x: torch.Tensor, n_inner: int, name: str):
@@ -78,57 +116,60 @@ def _prep_z(z, device):
     if z.numel() != 1:
         raise ValueError("bkcore: z must hold exactly one value")
     if z.is_cuda:
-        zz = z.detach().reshape(())
-        if zz.device != device:
-            zz = zz.to(device)
-        if zz.dtype != torch.complex64:
-            zz = zz.to(torch.complex64)
-        zr = torch.view_as_real(zz.contiguous())
-        return zr, zr.data_ptr(), 0.0, 0.0
+        # a complex64 element is the (re, im) float pair the kernels read: no view, no copy, no host sync
+        if z.dtype == torch.complex64 and z.device == device:
+            return z, z.data_ptr(), 0.0, 0.0
+        zz = z.detach().reshape(()).to(device=device, dtype=torch.complex64)
+        return zz, zz.data_ptr(), 0.0, 0.0
     zc = complex(z.detach().reshape(()).item())
     return None, None, float(zc.real), float(zc.imag)
 
 
 def bk_forward(a, b, c, z, raw: bool = False, phi_exact: bool = False, want_features: bool = True,
-               feature_clamp=None):
+               feature_clamp=None, share_storage: bool = False):
     """Launch the HIP forward.  a (B,N), b/c (B,N-1) real tensors on the GPU.  Returns (features|None, G).
-    feature_clamp: the features come out clamped to +-feature_clamp (G does not)."""
+    feature_clamp: the features come out clamped to +-feature_clamp (G does not).
+    share_storage: without a clamp the features are bit for bit the (re, im) pairs of G (bk_core.py:296-298), so they
+    are returned as the float32 view of G instead of a second 8-byte-per-element write."""
     L = _lib.load()
     a, b, c, dt = _prep_inputs(a, b, c)
     B, N = a.shape
     nb = max(N - 1, 0)
     G = torch.empty((B, N), dtype=torch.complex64, device=a.device)
-    feats = torch.empty((B, N, 2), dtype=torch.float32, device=a.device) if want_features else None
+    if want_features and share_storage and feature_clamp is None:
+        feats_out = torch.view_as_real(G)
+        feats = None                                   # nothing for the kernel to write
+    else:
+        feats = torch.empty((B, N, 2), dtype=torch.float32, device=a.device) if want_features else None
+        feats_out = feats
     if B == 0 or N == 0:
-        return feats, G
+        return feats_out, G
     a, pa, lda = _rows(a, N, "a")
     b, pb, ldb = _rows(b, nb, "b")
     c, pc, ldc = _rows(c, nb, "c")
-    with torch.cuda.device(a.device):
+    dev = a.device
+    with _on_device(dev):
         stream = torch.cuda.current_stream().cuda_stream
-        zkeep, pz, zre, zim = _prep_z(z, a.device)
-        state = _state_block(a.device, stream)
+        zkeep, pz, zre, zim = _prep_z(z, dev)
+        state = _state_block(dev, stream)
         flags = (_lib.FLAG_RAW if raw else 0) | (_lib.FLAG_PHI_EXACT if phi_exact else 0) \
             | (_lib.FLAG_SCAN_PATH if _DEBUG["scan_path"] else 0)
-        ws_bytes = int(L.bkcore_workspace_bytes(B, N))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
-        if feature_clamp is None:
-            rc = L.bkcore_forward(pa, lda, pb if nb else None, ldb, pc if nb else None, ldc, dt, pz, zre, zim, B, N,
-                                  G.data_ptr(), feats.data_ptr() if feats is not None else None,
-                                  ws.data_ptr() if ws is not None else None, ws_bytes,
-                                  state.data_ptr() if state is not None else None, flags, stream)
-        else:
-            if not float(feature_clamp) > 0.0:
+        ws, ws_bytes = _workspace(L, dev, stream, B, N)
+        if _DEBUG["keep_ws"]:       # diagnostics read the workspace after the call: give this call its own
+            ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
+        fc = 0.0
+        if feature_clamp is not None:
+            fc = float(feature_clamp)
+            if not fc > 0.0:
                 raise ValueError("bkcore: feature_clamp must be positive")
-            rc = L.bkcore_forward_clamped(pa, lda, pb if nb else None, ldb, pc if nb else None, ldc, dt, pz, zre, zim,
-                                          B, N, G.data_ptr(), feats.data_ptr() if feats is not None else None,
-                                          float(feature_clamp), ws.data_ptr() if ws is not None else None, ws_bytes,
-                                          state.data_ptr() if state is not None else None, flags, stream)
+        rc = L.bkcore_forward_clamped(pa, lda, pb if nb else None, ldb, pc if nb else None, ldc, dt, pz, zre, zim,
+                                      B, N, G.data_ptr(), feats.data_ptr() if feats is not None else None, fc,
+                                      ws.data_ptr(), ws_bytes, state.data_ptr(), flags, stream)
     _lib.check(rc, "bkcore_forward")
     del zkeep
     if _DEBUG["keep_ws"]:
         _DEBUG["last_ws"], _DEBUG["last_B"] = ws, B
-    return feats, G
+    return feats_out, G
 
 
 def rows_recomputed():
@@ -160,7 +201,7 @@ def bk_backward_reference(G, grad_features, grad_G, alpha: float):
         if gg.dtype != torch.complex64:
             gg = gg.to(torch.complex64)
         gg = gg.contiguous()
-    with torch.cuda.device(G.device):
+    with _on_device(G.device):
         stream = torch.cuda.current_stream().cuda_stream
         rc = L.bkcore_backward_ref(G.data_ptr(), gf.data_ptr() if gf is not None else None,
                                    gg.data_ptr() if gg is not None else None, float(alpha), n, out.data_ptr(), stream)
@@ -190,7 +231,7 @@ def layer_prologue(v_pre, h0_diag, v_max: float, out_dtype=torch.bfloat16):
     out = torch.empty((B, N), dtype=out_dtype, device=v.device)
     if B == 0 or N == 0:
         return out
-    with torch.cuda.device(v.device):
+    with _on_device(v.device):
         stream = torch.cuda.current_stream().cuda_stream
         rc = L.bkcore_layer_prologue(v.data_ptr(), v.stride(0) if B > 1 else N, h0.data_ptr(), float(v_max), B, N,
                                      out.data_ptr(), _lib.BF16 if out_dtype == torch.bfloat16 else _lib.F32, stream)
@@ -213,7 +254,7 @@ def layer_backward_reference(G, grad_features, grad_G, alpha: float, feature_cla
         return out
     gf = grad_features.float().contiguous() if grad_features is not None else None
     gg = grad_G.to(torch.complex64).contiguous() if grad_G is not None else None
-    with torch.cuda.device(G.device):
+    with _on_device(G.device):
         stream = torch.cuda.current_stream().cuda_stream
         rc = L.bkcore_layer_backward_ref(G.data_ptr(), gf.data_ptr() if gf is not None else None,
                                          gg.data_ptr() if gg is not None else None, float(alpha),
@@ -271,7 +312,7 @@ def bk_backward_analytic(a, b, c, z, grad_features, grad_G, phi_exact: bool = Fa
         gg = grad_G.to(torch.complex64).contiguous()
         if tuple(gg.shape) != (B, N):
             raise ValueError("bkcore: grad_G must have shape (B, N)")
-    with torch.cuda.device(a.device):
+    with _on_device(a.device):
         stream = torch.cuda.current_stream().cuda_stream
         zkeep, pz, zre, zim = _prep_z(z, a.device)
         state = _state_block(a.device, stream)
@@ -316,6 +357,9 @@ class BKCoreFunction(torch.autograd.Function):
     PHI_K_INDEX = "reference"
     GRAD_MODE = "reference"
     WARN_NONFINITE_GRAD = False     # True: check the incoming gradient on the host and warn as bk_core.py:321-325 does
+    SHARE_FEATURES_STORAGE = True   # features = the float32 view of G_ii (same numbers, bk_core.py:296-298) instead of
+                                    # a second tensor: halves the bytes the forward writes.  An in-place modification
+                                    # of either output then raises in autograd; False gives two separate tensors
 
     @staticmethod
     def forward(ctx, he_diag, h0_super, h0_sub, z, use_triton=None, use_parallel_scan=None):
@@ -325,7 +369,8 @@ class BKCoreFunction(torch.autograd.Function):
         b2 = h0_super.reshape(-1, max(n - 1, 0)) if h0_super.dim() != 2 else h0_super
         c2 = h0_sub.reshape(-1, max(n - 1, 0)) if h0_sub.dim() != 2 else h0_sub
         feats, G = bk_forward(a2.detach(), b2.detach(), c2.detach(), z, raw=False,
-                              phi_exact=(BKCoreFunction.PHI_K_INDEX == "exact"))
+                              phi_exact=(BKCoreFunction.PHI_K_INDEX == "exact"),
+                              share_storage=BKCoreFunction.SHARE_FEATURES_STORAGE)
         if he_diag.dim() != 2:
             feats = feats.reshape(*lead, n, 2)
             G = G.reshape(*lead, n)
@@ -449,7 +494,7 @@ class FusedSpectralOutputFunction(torch.autograd.Function):
             res = residual.detach().float().contiguous()
         out = torch.empty((*lead, D), dtype=torch.float32, device=f.device)
         if n and D:
-            with torch.cuda.device(f.device):
+            with _on_device(f.device):
                 rc = L.bkcore_layer_epilogue(f.data_ptr(), w.data_ptr(), bb.data_ptr(), sc.data_ptr(),
                                              res.data_ptr() if res is not None else None, n, D, out.data_ptr(),
                                              torch.cuda.current_stream().cuda_stream)
@@ -471,7 +516,7 @@ class FusedSpectralOutputFunction(torch.autograd.Function):
         gb = torch.empty_like(bb) if need_b else None
         gs = torch.empty_like(sc) if need_s else None
         if n and D:
-            with torch.cuda.device(f.device):
+            with _on_device(f.device):
                 nbytes = int(L.bkcore_layer_epilogue_backward_workspace_bytes(n, D))
                 ws = torch.empty(nbytes, dtype=torch.uint8, device=f.device)
                 ptr = lambda t: t.data_ptr() if t is not None else None

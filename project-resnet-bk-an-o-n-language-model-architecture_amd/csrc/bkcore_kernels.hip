@@ -1045,38 +1045,45 @@ __device__ __forceinline__ float bwd_ref_one(float2 G, float2 g, float alpha) {
   return gv;
 }
 
+// Four elements per thread per iteration: two 16-byte loads of G and of each cotangent (read once: nontemporal), one
+// 16-byte store.  The loads need only the 8-byte alignment of a complex64 / float pair.
+typedef float bk_v4f __attribute__((ext_vector_type(4)));
+struct __attribute__((aligned(8))) V4a8 { bk_v4f v; };
+struct __attribute__((aligned(4))) V4a4 { bk_v4f v; };
 template <bool HAS_GF, bool HAS_GG>
 __global__ __launch_bounds__(256) void bk_backward_ref_kernel(const float2 *__restrict__ G, const float2 *__restrict__ gf,
                                                               const float2 *__restrict__ gG, float alpha, long n,
                                                               float *__restrict__ out) {
   const long stride = (long)gridDim.x * blockDim.x;
-  // two elements per thread per iteration: 16-byte loads of G / grads, 8-byte store
-  const long npairs = n >> 1;
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npairs; p += stride) {
-    const float4 Gv = reinterpret_cast<const float4 *>(G)[p];
-    float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long nquads = n >> 2;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < nquads; p += stride) {
+    const V4a8 *Gq = reinterpret_cast<const V4a8 *>(G + 4 * p);
+    const bk_v4f G0 = __builtin_nontemporal_load(&Gq[0].v), G1 = __builtin_nontemporal_load(&Gq[1].v);
+    bk_v4f g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
     if (HAS_GF) {
-      gv = reinterpret_cast<const float4 *>(gf)[p];
-      gv.x = nan_to_num_default(gv.x);
-      gv.y = nan_to_num_default(gv.y);
-      gv.z = nan_to_num_default(gv.z);
-      gv.w = nan_to_num_default(gv.w);
+      const V4a8 *q = reinterpret_cast<const V4a8 *>(gf + 4 * p);
+      g0 = __builtin_nontemporal_load(&q[0].v);
+      g1 = __builtin_nontemporal_load(&q[1].v);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        g0[i] = nan_to_num_default(g0[i]);
+        g1[i] = nan_to_num_default(g1[i]);
+      }
     }
     if (HAS_GG) {
-      const float4 q = reinterpret_cast<const float4 *>(gG)[p];
-      gv.x += q.x;
-      gv.y += q.y;
-      gv.z += q.z;
-      gv.w += q.w;
+      const V4a8 *q = reinterpret_cast<const V4a8 *>(gG + 4 * p);
+      g0 += __builtin_nontemporal_load(&q[0].v);
+      g1 += __builtin_nontemporal_load(&q[1].v);
     }
-    float2 o;
-    o.x = bwd_ref_one(make_float2(Gv.x, Gv.y), make_float2(gv.x, gv.y), alpha);
-    o.y = bwd_ref_one(make_float2(Gv.z, Gv.w), make_float2(gv.z, gv.w), alpha);
-    __builtin_nontemporal_store(o.x, &out[2 * p]);
-    __builtin_nontemporal_store(o.y, &out[2 * p + 1]);
+    bk_v4f o;
+    o[0] = bwd_ref_one(make_float2(G0[0], G0[1]), make_float2(g0[0], g0[1]), alpha);
+    o[1] = bwd_ref_one(make_float2(G0[2], G0[3]), make_float2(g0[2], g0[3]), alpha);
+    o[2] = bwd_ref_one(make_float2(G1[0], G1[1]), make_float2(g1[0], g1[1]), alpha);
+    o[3] = bwd_ref_one(make_float2(G1[2], G1[3]), make_float2(g1[2], g1[3]), alpha);
+    __builtin_nontemporal_store(o, &reinterpret_cast<V4a4 *>(out + 4 * p)->v);
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-    const long i = n - 1;
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = (n & ~3L) + threadIdx.x;
     float2 g = make_float2(0.f, 0.f);
     if (HAS_GF) g = make_float2(nan_to_num_default(gf[i].x), nan_to_num_default(gf[i].y));
     if (HAS_GG) { g.x += gG[i].x; g.y += gG[i].y; }
@@ -1382,8 +1389,8 @@ int bkcore_backward_ref(const float *G, const float *grad_features, const float 
   if (n == 0) return BKCORE_OK;
   if (!G || !grad_a) return BKCORE_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const long pairs = (n + 1) / 2;
-  long blocks = (pairs + 255) / 256;
+  const long quads = (n + 3) / 4;
+  long blocks = (quads + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   const dim3 grid((unsigned)blocks), block(256);

@@ -245,9 +245,9 @@ __device__ __forceinline__ void load_ratio(const TIn *__restrict__ a, const TIn 
 #pragma unroll
     for (int j = 0; j < RNJ; ++j) {
       const int q = min(t + j * RT, RN);
-      av[j] = to_f32<TIn>(a0[q]);
-      bv[j] = to_f32<TIn>(b0[q]);
-      cv[j] = to_f32<TIn>(c0[q]);
+      av[j] = to_f32<TIn>(__builtin_nontemporal_load(a0 + q));  // each input is read once (plus a halo's worth)
+      bv[j] = to_f32<TIn>(__builtin_nontemporal_load(b0 + q));
+      cv[j] = to_f32<TIn>(__builtin_nontemporal_load(c0 + q));
     }
   } else {
     // branch-free: every load uses a clamped, always valid index (b and c must be readable at index 0 even when the
