@@ -546,13 +546,32 @@ __device__ __forceinline__ void sweepB_range(const TIn *__restrict__ a, const TI
 }
 
 
+// The state block: state[0] a NaN was seen in he_diag, state[1] a NaN was seen in b or c, state[2] some row failed its
+// checks -- raised (to 1) by the first launch(es) of a call, read by every workgroup of the call's last launch, which
+// is always the second-launch form of bk_forward_kernel.  Clean calls leave the block all zero and cost nothing.  When
+// a flag is up, every workgroup of that last launch takes a ticket in state[4] once it has read the flags and done its
+// work, and the last ticket puts the block back to zero for the next call on the stream.  All of it lives on the
+// device, so a captured forward replays correctly in a HIP graph.
+__device__ __forceinline__ void state_release(int *state) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int ticket = __hip_atomic_fetch_add(&state[4], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == (int)gridDim.x - 1) {
+      __hip_atomic_store(&state[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&state[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&state[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&state[4], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // FAST = first launch (fast pass 1, verified); !FAST = second launch: rows whose verification failed, or every row
 // when he_diag held a NaN and b/c held a NaN (then with b/c NaNs replaced by 1, bk_core.py:260-264).
 template <typename TIn, bool PHI_EXACT, bool FAST, bool SAVE>
 __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
     const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
     const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, float2 *__restrict__ G_,
-    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, int second, unsigned flags, float fclamp,
+    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int second, unsigned flags, float fclamp,
     float2 *__restrict__ save_r_, float2 *__restrict__ save_s_) {
   __shared__ Shared sh;
   const long row = blockIdx.x;
@@ -562,9 +581,13 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
     const int sa = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int sb = __hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int sc = __hip_atomic_load(&state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    fix_bc = (sa == call_id && sb == call_id) && !(flags & BKCORE_FLAG_RAW);
-    const bool redo_row = (sc == call_id) && rowflag[row] != 0;
-    if (!fix_bc && !redo_row) return;
+    if (!(sa | sb | sc)) return;  // nothing was flagged by the first launch: the usual case
+    fix_bc = (sa != 0 && sb != 0) && !(flags & BKCORE_FLAG_RAW);
+    const bool redo_row = sc != 0 && rowflag[row] != 0;
+    if (!fix_bc && !redo_row) {
+      state_release(state);
+      return;
+    }
   }
   const TIn *a = a_ + row * lda;
   const TIn *b = b_ + row * ldb;
@@ -617,13 +640,14 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
     const int any_bad = __syncthreads_or(bad ? 1 : 0);
     if (t == 0) {
       rowflag[row] = any_bad;
-      if (any_bad) __hip_atomic_store(&state[2], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (any_bad) __hip_atomic_store(&state[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (state && !second && seen) {
-    if (seen & 1u) __hip_atomic_store(&state[0], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (seen & 2u) __hip_atomic_store(&state[1], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen & 1u) __hip_atomic_store(&state[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen & 2u) __hip_atomic_store(&state[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (second) state_release(state);
 }
 
 // ---- long rows, few of them: several workgroups per row --------------------------------------------------------
@@ -737,8 +761,7 @@ __device__ __forceinline__ bool ratio_differs_tight(const Vec &est, const Vec &x
 template <typename TIn, bool PHI_EXACT>
 __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_split_aggregate_kernel(
     const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
-    const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, char *__restrict__ ws, int *state,
-    int call_id, unsigned flags, int S, int seg_ch) {
+    const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, char *__restrict__ ws, int *state, unsigned flags, int S, int seg_ch) {
   __shared__ Shared sh;
   const long row = blockIdx.x / S;
   const int sg = blockIdx.x % S;
@@ -835,8 +858,8 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_split_aggregate_kerne
     info[23] = any_bad ? 1.0f : 0.0f;
   }
   if (state && seen) {
-    if (seen & 1u) __hip_atomic_store(&state[0], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (seen & 2u) __hip_atomic_store(&state[1], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen & 1u) __hip_atomic_store(&state[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen & 2u) __hip_atomic_store(&state[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -877,8 +900,7 @@ __device__ __forceinline__ Scal sshfl(const Scal &v, int d) {
 // segment's outgoing state, forms the running factors of theta (C_s, left to right) and phi (D_s, right to left)
 // as products of complex scalars with exponents (wave scans over shuffles), and writes each segment's epilogue
 // factor C_s D_s / theta_N.
-__global__ __launch_bounds__(64) void bk_split_combine_kernel(long B, long N, char *__restrict__ ws, int *state,
-                                                              int call_id, int S) {
+__global__ __launch_bounds__(64) void bk_split_combine_kernel(long B, long N, char *__restrict__ ws, int *state, int S) {
   __shared__ float cm[3][MAX_SEGMENTS];
   const long row = blockIdx.x;
   const int lane = threadIdx.x;
@@ -959,7 +981,7 @@ __global__ __launch_bounds__(64) void bk_split_combine_kernel(long B, long N, ch
   const int any_bad = __syncthreads_or(bad ? 1 : 0);
   if (lane == 0) {
     rowflag[row] = any_bad ? 1 : 0;
-    if (any_bad) __hip_atomic_store(&state[2], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (any_bad) __hip_atomic_store(&state[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -967,7 +989,7 @@ template <typename TIn, bool PHI_EXACT>
 __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_split_output_kernel(
     const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
     const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, float2 *__restrict__ G_,
-    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, unsigned flags, float fclamp, int S,
+    float2 *__restrict__ F_, char *__restrict__ ws, int *state, unsigned flags, float fclamp, int S,
     int seg_ch) {
   __shared__ Shared sh;
   const long row = blockIdx.x / S;
@@ -1012,7 +1034,7 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_split_output_kernel(
   const int any_bad = __syncthreads_or(bad ? 1 : 0);
   if (t == 0 && any_bad) {
     atomicOr(&rowflag[row], 1);
-    __hip_atomic_store(&state[2], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&state[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1182,7 +1204,6 @@ __global__ __launch_bounds__(256) void bk_layer_backward_ref_kernel(const float2
 }
 
 thread_local int g_last_hip_error = 0;
-int g_call_counter = 0;
 
 // How a (B, N) problem is cut: segments per row (1 = one workgroup per row) and chunks per segment, in chunks of
 // `chunk` elements (the tile of the kernel that will run: the ratio-form kernel's or the scan kernel's).  Rows are cut
@@ -1213,18 +1234,10 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
                     const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
                     void *ws, void *state, unsigned flags, hipStream_t stream, float *save_r, float *save_s,
                     float fclamp = __builtin_huge_valf()) {
-  int call_id = 0;
-  if (state) {
-    call_id = __atomic_add_fetch(&g_call_counter, 1, __ATOMIC_RELAXED);
-    if (call_id <= 0) {  // wrapped: restart above zero
-      __atomic_store_n(&g_call_counter, 1, __ATOMIC_RELAXED);
-      call_id = 1;
-    }
-  }
 #define BK_LAUNCH(FASTV, SECOND)                                                                                     \
   hipLaunchKernelGGL((bk_forward_kernel<TIn, PHI_EXACT, FASTV, SAVE>), dim3((unsigned)B), dim3(T), 0, stream,        \
                      (const TIn *)a, (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re,   \
-                     z_im, (long)B, (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id,     \
+                     z_im, (long)B, (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state,     \
                      SECOND, flags, fclamp, (float2 *)save_r, (float2 *)save_s)
   int S = 1, seg_ch = 0;
   if (state && !SAVE)
@@ -1233,10 +1246,10 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
     // few long rows, ratio form: segment products, combine, segment outputs, then the (normally empty) launch of
     // the scan kernel for rows whose checks failed
     bkcore_internal_ratio_forward(dtype_tag<TIn>(), PHI_EXACT, 1, 0, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G,
-                                  features, ws, state, call_id, flags, fclamp, S, seg_ch, nullptr, nullptr, stream);
-    bkcore_internal_ratio_combine(B, N, ws, state, call_id, S, stream);
+                                  features, ws, state, flags, fclamp, S, seg_ch, nullptr, nullptr, stream);
+    bkcore_internal_ratio_combine(B, N, ws, state, S, stream);
     bkcore_internal_ratio_forward(dtype_tag<TIn>(), PHI_EXACT, 2, 0, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G,
-                                  features, ws, state, call_id, flags, fclamp, S, seg_ch, nullptr, nullptr, stream);
+                                  features, ws, state, flags, fclamp, S, seg_ch, nullptr, nullptr, stream);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) {
       BK_LAUNCH(false, 1);
@@ -1251,12 +1264,12 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
     const unsigned grid = (unsigned)(B * S);
     hipLaunchKernelGGL((bk_split_aggregate_kernel<TIn, PHI_EXACT>), dim3(grid), dim3(T), 0, stream, (const TIn *)a,
                        (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re, z_im, (long)B,
-                       (long)N, (char *)ws, (int *)state, call_id, flags, S, seg_ch);
+                       (long)N, (char *)ws, (int *)state, flags, S, seg_ch);
     hipLaunchKernelGGL(bk_split_combine_kernel, dim3((unsigned)B), dim3(64), 0, stream, (long)B, (long)N,
-                       (char *)ws, (int *)state, call_id, S);
+                       (char *)ws, (int *)state, S);
     hipLaunchKernelGGL((bk_split_output_kernel<TIn, PHI_EXACT>), dim3(grid), dim3(T), 0, stream, (const TIn *)a,
                        (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re, z_im, (long)B,
-                       (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id, flags, fclamp, S,
+                       (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state, flags, fclamp, S,
                        seg_ch);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) {
@@ -1270,7 +1283,7 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
   } else if (state && !(flags & BKCORE_FLAG_SCAN_PATH)) {
     // single-sweep ratio-form first launch, then the (normally empty) second launch for rows whose checks failed
     bkcore_internal_ratio_forward(dtype_tag<TIn>(), PHI_EXACT, 0, SAVE, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G,
-                                  features, ws, state, call_id, flags, fclamp, 1, 0, save_r, save_s, stream);
+                                  features, ws, state, flags, fclamp, 1, 0, save_r, save_s, stream);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) {
       BK_LAUNCH(false, 1);

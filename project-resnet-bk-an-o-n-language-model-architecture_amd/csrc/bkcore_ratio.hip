@@ -352,7 +352,7 @@ template <typename TIn, bool PHI_EXACT, int MODE, bool SAVE = false>
 __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE) ? BK_RATIO_WAVES : 2) void bk_ratio_forward_kernel(
     const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
     const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, float2 *__restrict__ G_,
-    float2 *__restrict__ F_, char *__restrict__ ws, int *state, int call_id, unsigned flags, float fclamp, int S,
+    float2 *__restrict__ F_, char *__restrict__ ws, int *state, unsigned flags, float fclamp, int S,
     int seg_ch, float2 *__restrict__ save_r_ = nullptr, float2 *__restrict__ save_s_ = nullptr) {
   __shared__ SharedR sh;
   const long row = MODE == 0 ? (long)blockIdx.x : (long)(blockIdx.x / S);
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE) ? BK_RATIO_WAVES : 2) void
   if (t == 0) {
     if (MODE == 0) {
       rowflag[row] = any_bad;
-      if (any_bad) __hip_atomic_store(&state[2], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (any_bad) __hip_atomic_store(&state[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (MODE == 1) {
       const Prod tot = sh.carry[nscan & 1];  // started from one: the segment's own product
       info[0] = tot.m.x;
@@ -692,19 +692,18 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE) ? BK_RATIO_WAVES : 2) void
       info[3] = any_bad ? 1.0f : 0.0f;
     } else if (any_bad) {
       atomicOr(&rowflag[row], 1);
-      __hip_atomic_store(&state[2], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&state[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (seen) {
-    if (seen & 1u) __hip_atomic_store(&state[0], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (seen & 2u) __hip_atomic_store(&state[1], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen & 1u) __hip_atomic_store(&state[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen & 2u) __hip_atomic_store(&state[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
 // One wave per row, one lane per segment (64 at a time, right to left): the product entering each segment, the
 // checks across segment boundaries, the row's verdict.
-__global__ __launch_bounds__(64) void bk_ratio_combine_kernel(long B, long N, char *__restrict__ ws, int *state,
-                                                              int call_id, int S) {
+__global__ __launch_bounds__(64) void bk_ratio_combine_kernel(long B, long N, char *__restrict__ ws, int *state, int S) {
   const long row = blockIdx.x;
   const int lane = threadIdx.x;
   int *rowflag = reinterpret_cast<int *>(ws);
@@ -755,7 +754,7 @@ __global__ __launch_bounds__(64) void bk_ratio_combine_kernel(long B, long N, ch
   const int any_bad = __syncthreads_or(bad ? 1 : 0);
   if (lane == 0) {
     rowflag[row] = any_bad ? 1 : 0;
-    if (any_bad) __hip_atomic_store(&state[2], call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (any_bad) __hip_atomic_store(&state[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -765,12 +764,12 @@ namespace {
 template <typename TIn, bool PHI_EXACT>
 void ratio_launch(int mode, int save, const void *a, long lda, const void *b, long ldb, const void *c, long ldc,
                   const float *z_dev, float z_re, float z_im, long B, long N, float *G, float *features, void *ws,
-                  void *state, int call_id, unsigned flags, float fclamp, int S, int seg_ch, float *save_r,
+                  void *state, unsigned flags, float fclamp, int S, int seg_ch, float *save_r,
                   float *save_s, hipStream_t stream) {
 #define BK_RATIO(MODE, SAVE, GRID)                                                                                   \
   hipLaunchKernelGGL((bk_ratio_forward_kernel<TIn, PHI_EXACT, MODE, SAVE>), dim3((unsigned)(GRID)), dim3(RT), 0,      \
                      stream, (const TIn *)a, lda, (const TIn *)b, ldb, (const TIn *)c, ldc, z_dev, z_re, z_im, B, N, \
-                     (float2 *)G, (float2 *)features, (char *)ws, (int *)state, call_id, flags, fclamp, S, seg_ch,   \
+                     (float2 *)G, (float2 *)features, (char *)ws, (int *)state, flags, fclamp, S, seg_ch,   \
                      (float2 *)save_r, (float2 *)save_s)
   if (mode == 1) BK_RATIO(1, false, B * S);
   else if (mode == 2) BK_RATIO(2, false, B * S);
@@ -783,18 +782,18 @@ void ratio_launch(int mode, int save, const void *a, long lda, const void *b, lo
 extern "C" void bkcore_internal_ratio_forward(int in_dtype, int phi_exact, int mode, int save, const void *a,
                                               int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
                                               const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G,
-                                              float *features, void *ws, void *state, int call_id, unsigned flags,
+                                              float *features, void *ws, void *state, unsigned flags,
                                               float fclamp, int S, int seg_ch, float *save_r, float *save_s,
                                               void *stream) {
 #define BK_DISPATCH(TIN)                                                                                             \
   do {                                                                                                               \
     if (phi_exact)                                                                                                   \
       ratio_launch<TIN, true>(mode, save, a, (long)lda, b, (long)ldb, c, (long)ldc, z_dev, z_re, z_im, (long)B,      \
-                              (long)N, G, features, ws, state, call_id, flags, fclamp, S, seg_ch, save_r, save_s,    \
+                              (long)N, G, features, ws, state, flags, fclamp, S, seg_ch, save_r, save_s,    \
                               (hipStream_t)stream);                                                                  \
     else                                                                                                             \
       ratio_launch<TIN, false>(mode, save, a, (long)lda, b, (long)ldb, c, (long)ldc, z_dev, z_re, z_im, (long)B,     \
-                               (long)N, G, features, ws, state, call_id, flags, fclamp, S, seg_ch, save_r, save_s,   \
+                               (long)N, G, features, ws, state, flags, fclamp, S, seg_ch, save_r, save_s,   \
                                (hipStream_t)stream);                                                                 \
   } while (0)
   switch (in_dtype) {
@@ -811,8 +810,8 @@ extern "C" void bkcore_internal_ratio_forward(int in_dtype, int phi_exact, int m
 
 extern "C" int bkcore_internal_ratio_chunk(void) { return RCHUNK; }
 
-extern "C" void bkcore_internal_ratio_combine(int64_t B, int64_t N, void *ws, void *state, int call_id, int S,
+extern "C" void bkcore_internal_ratio_combine(int64_t B, int64_t N, void *ws, void *state, int S,
                                               void *stream) {
   hipLaunchKernelGGL(bk_ratio_combine_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, (long)B, (long)N,
-                     (char *)ws, (int *)state, call_id, S);
+                     (char *)ws, (int *)state, S);
 }
