@@ -45,6 +45,7 @@ extern "C" {
 #define BKCORE_ETOOLONG (-2) /* N larger than bkcore_max_seq_len() */
 #define BKCORE_ELAUNCH (-3)  /* HIP launch failed; bkcore_last_hip_error() has the HIP code */
 #define BKCORE_EWORKSPACE (-4) /* workspace missing or smaller than bkcore_workspace_bytes(B, N) */
+#define BKCORE_ETOOBIG (-5)  /* bkcore_forward_noalloc: bkcore_workspace_bytes(B, N) exceeds BKCORE_NOALLOC_MAX_WORKSPACE */
 
 /* Size in bytes of the persistent per-(device,stream) state block bkcore_forward may be given.
  * Allocate once with device memory, zero it once, reuse it for every call on that stream. */
@@ -130,6 +131,23 @@ int bkcore_forward_clamped(const void *a, int64_t lda, const void *b, int64_t ld
                            int in_dtype, const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G,
                            float *features, float feature_clamp, void *workspace, size_t workspace_bytes, void *state,
                            unsigned flags, void *stream);
+
+/*
+ * bkcore_forward_clamped without a workspace and without a state block from the caller: both live in a fixed array of
+ * device memory that is part of the library's code object (BKCORE_NOALLOC_MAX_WORKSPACE + 256 bytes on every GPU the
+ * library runs on, held until the process ends).  The call allocates and frees nothing, on the host or the device.
+ * No counterpart in the reference; it is for callers that cannot allocate: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.
+ *
+ * Limit: bkcore_workspace_bytes(B, N) <= BKCORE_NOALLOC_MAX_WORKSPACE, else BKCORE_ETOOBIG and nothing is launched
+ * (4 bytes per row + 5120 bytes per row and started 4096-element chunk: e.g. B = 256 rows of N = 24576, or B = 8 of
+ * N = 2^19).  Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads)
+ * race on it; calls on one stream are ordered and safe.  All other arguments and results as bkcore_forward_clamped.
+ */
+#define BKCORE_NOALLOC_MAX_WORKSPACE (8u << 20)
+int bkcore_forward_noalloc(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
+                           int in_dtype, const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G,
+                           float *features, float feature_clamp, unsigned flags, void *stream);
 
 /*
  * The caller's elementwise steps in front of the operator, in one pass: replaces the tensor-library chain of

@@ -30,6 +30,9 @@
 // launch: only rows whose verification failed, with pass 1 as a full scan too.
 #include "bkcore_device.h"
 
+// Device memory of bkcore_forward_noalloc (one copy per GPU the library runs on, held until the process ends).
+static __device__ __align__(256) unsigned char bk_static_scratch[256 + BKCORE_NOALLOC_MAX_WORKSPACE];
+
 namespace {
 
 
@@ -1205,6 +1208,12 @@ __global__ __launch_bounds__(256) void bk_layer_backward_ref_kernel(const float2
 
 thread_local int g_last_hip_error = 0;
 
+// Scratch of bkcore_forward_noalloc: state block + workspace in device memory that belongs to the code object.
+constexpr size_t STATIC_STATE_BYTES = 256;
+constexpr size_t STATIC_WS_BYTES = (size_t)BKCORE_NOALLOC_MAX_WORKSPACE;
+constexpr int MAX_DEVICES = 64;
+unsigned char *g_static_scratch_ptr[MAX_DEVICES] = {};
+
 // How a (B, N) problem is cut: segments per row (1 = one workgroup per row) and chunks per segment, in chunks of
 // `chunk` elements (the tile of the kernel that will run: the ratio-form kernel's or the scan kernel's).  Rows are cut
 // only when there are too few of them to occupy half of the 256 CUs and they are long enough (measured break-even:
@@ -1384,6 +1393,39 @@ int bkcore_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const
                                 workspace_bytes, state, flags, stream);
 }
 
+int bkcore_forward_noalloc(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
+                           int in_dtype, const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G,
+                           float *features, float feature_clamp, unsigned flags, void *stream) {
+  if (B < 0 || N < 0) return BKCORE_EINVAL;
+  if (B == 0 || N == 0) return BKCORE_OK;
+  if (N > bkcore_max_seq_len()) return BKCORE_ETOOLONG;
+  const size_t need = bkcore_workspace_bytes(B, N);
+  if (need > STATIC_WS_BYTES) return BKCORE_ETOOBIG;
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+    g_last_hip_error = (int)e;
+    return e != hipSuccess ? BKCORE_ELAUNCH : BKCORE_EINVAL;
+  }
+  // each device holds its own copy of the array at its own address: looked up once per device, with that device
+  // current, and kept; the array's name itself is never passed to a kernel
+  unsigned char *base = __atomic_load_n(&g_static_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (!base) {
+    void *p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(bk_static_scratch));
+    if (e != hipSuccess || !p) {
+      g_last_hip_error = (int)e;
+      return BKCORE_ELAUNCH;
+    }
+    base = static_cast<unsigned char *>(p);
+    __atomic_store_n(&g_static_scratch_ptr[dev], base, __ATOMIC_RELEASE);
+  }
+  // [0, STATIC_STATE_BYTES): the state block (zero when the library is loaded, self-clearing afterwards);
+  // behind it the workspace, which every call writes before it reads
+  return bkcore_forward_clamped(a, lda, b, ldb, c, ldc, in_dtype, z_dev, z_re, z_im, B, N, G, features, feature_clamp,
+                                base + STATIC_STATE_BYTES, need, base, flags, stream);
+}
+
 int bkcore_internal_forward_save(const float *a, int64_t lda, const float *b, int64_t ldb, const float *c, int64_t ldc,
                                  const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G,
                                  void *workspace, void *state, unsigned flags, void *stream, float *save_r,
@@ -1488,7 +1530,7 @@ int bkcore_layer_backward_ref(const float *G, const float *grad_features, const 
 int64_t bkcore_max_seq_len(void) { return (int64_t)MAX_N; }
 int bkcore_last_hip_error(void) { return g_last_hip_error; }
 void bkcore_internal_set_hip_error(int code) { g_last_hip_error = code; }
-int bkcore_abi_version(void) { return 8; }
+int bkcore_abi_version(void) { return 9; }
 
 const char *bkcore_error_string(int code) {
   switch (code) {
@@ -1497,6 +1539,7 @@ const char *bkcore_error_string(int code) {
     case BKCORE_ETOOLONG: return "sequence length exceeds bkcore_max_seq_len()";
     case BKCORE_ELAUNCH: return "HIP kernel launch failed (see bkcore_last_hip_error())";
     case BKCORE_EWORKSPACE: return "workspace missing or smaller than bkcore_workspace_bytes()";
+    case BKCORE_ETOOBIG: return "problem needs more scratch than bkcore_forward_noalloc holds (BKCORE_NOALLOC_MAX_WORKSPACE)";
     default: return "unknown bkcore error";
   }
 }
