@@ -23,6 +23,17 @@ extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_ratio_forw
 extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_ratio_combine(int64_t B, int64_t N, void *ws,
                                                                                    void *state, int S,
                                                                                    void *stream);
+// The same two launches with double-precision chains and product (bkcore_ratio_long.hip; no saving variant), taken for
+// rows longer than BKCORE_INTERNAL_LONG_ROW elements.
+#define BKCORE_INTERNAL_LONG_ROW 131072
+extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_ratio_forward_long(
+    int in_dtype, int phi_exact, int mode, int save, const void *a, int64_t lda, const void *b, int64_t ldb,
+    const void *c, int64_t ldc, const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G,
+    float *features, void *ws, void *state, unsigned flags, float fclamp, int S, int seg_ch, float *save_r,
+    float *save_s, void *stream);
+extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_ratio_combine_long(int64_t B, int64_t N, void *ws,
+                                                                                        void *state, int S,
+                                                                                        void *stream);
 // Elements per chunk of the ratio-form kernel (its workgroup size x 16).
 extern "C" __attribute__((visibility("hidden"))) int bkcore_internal_ratio_chunk(void);
 // Records the HIP error code that bkcore_last_hip_error() reports (per thread).

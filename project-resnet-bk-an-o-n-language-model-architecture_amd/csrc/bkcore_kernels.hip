@@ -1254,11 +1254,14 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
   if (S > 1 && !(flags & BKCORE_FLAG_SCAN_PATH)) {
     // few long rows, ratio form: segment products, combine, segment outputs, then the (normally empty) launch of
     // the scan kernel for rows whose checks failed
-    bkcore_internal_ratio_forward(dtype_tag<TIn>(), PHI_EXACT, 1, 0, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G,
-                                  features, ws, state, flags, fclamp, S, seg_ch, nullptr, nullptr, stream);
-    bkcore_internal_ratio_combine(B, N, ws, state, S, stream);
-    bkcore_internal_ratio_forward(dtype_tag<TIn>(), PHI_EXACT, 2, 0, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G,
-                                  features, ws, state, flags, fclamp, S, seg_ch, nullptr, nullptr, stream);
+    // rows beyond BKCORE_INTERNAL_LONG_ROW elements: chains and product in double
+    const auto fwd = N > BKCORE_INTERNAL_LONG_ROW ? bkcore_internal_ratio_forward_long : bkcore_internal_ratio_forward;
+    const auto comb = N > BKCORE_INTERNAL_LONG_ROW ? bkcore_internal_ratio_combine_long : bkcore_internal_ratio_combine;
+    fwd(dtype_tag<TIn>(), PHI_EXACT, 1, 0, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
+        flags, fclamp, S, seg_ch, nullptr, nullptr, stream);
+    comb(B, N, ws, state, S, stream);
+    fwd(dtype_tag<TIn>(), PHI_EXACT, 2, 0, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
+        flags, fclamp, S, seg_ch, nullptr, nullptr, stream);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) {
       BK_LAUNCH(false, 1);
@@ -1291,8 +1294,10 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
     }
   } else if (state && !(flags & BKCORE_FLAG_SCAN_PATH)) {
     // single-sweep ratio-form first launch, then the (normally empty) second launch for rows whose checks failed
-    bkcore_internal_ratio_forward(dtype_tag<TIn>(), PHI_EXACT, 0, SAVE, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G,
-                                  features, ws, state, flags, fclamp, 1, 0, save_r, save_s, stream);
+    const auto fwd = (N > BKCORE_INTERNAL_LONG_ROW && !SAVE) ? bkcore_internal_ratio_forward_long
+                                                             : bkcore_internal_ratio_forward;
+    fwd(dtype_tag<TIn>(), PHI_EXACT, 0, SAVE, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
+        flags, fclamp, 1, 0, save_r, save_s, stream);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) {
       BK_LAUNCH(false, 1);

@@ -2,7 +2,28 @@
 #include "bkcore_device.h"
 #include "bkcore_internal.h"
 
+// The arithmetic type of the chains and of the product, fixed per translation unit: float here; bkcore_ratio_long.hip
+// compiles this file again with double (BK_RATIO_REAL, BK_RATIO_LONG) for rows so long that the float32 rounding of
+// N ratios, a random walk of about 8.5e-8 sqrt(N) in the product, would use up the 1e-4 tolerance (3e-5 at N = 2^17,
+// 9e-5 at N = 2^20).
+#ifndef BK_RATIO_REAL
+#define BK_RATIO_REAL float
+#define BK_RATIO_LONG 0
+#endif
+
 namespace {
+
+typedef BK_RATIO_REAL Real;
+constexpr bool LONG = BK_RATIO_LONG != 0;
+typedef std::conditional<LONG, double2, float2>::type C2;
+__device__ __forceinline__ C2 c2(Real x, Real y) { C2 v; v.x = x; v.y = y; return v; }
+__device__ __forceinline__ C2 to_c2(float2 p) { return c2((Real)p.x, (Real)p.y); }
+__device__ __forceinline__ float2 to_f2(C2 p) { return make_float2((float)p.x, (float)p.y); }
+__device__ __forceinline__ float rfma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double rfma(double a, double b, double c) { return fma(a, b, c); }
+__device__ __forceinline__ C2 cmulr(C2 p, C2 q) {
+  return c2(rfma(p.x, q.x, -p.y * q.y), rfma(p.x, q.y, p.y * q.x));
+}
 
 // Tile of the ratio-form kernel: RT threads per workgroup, E elements per thread per chunk.  The workspace layout
 // (rowflag_bytes, lane_state_bytes) stays that of the scan kernel's tile.
@@ -83,34 +104,63 @@ constexpr int RAL_PAD = RN + RN / E + 8;        // float2 entries, index q + q/E
 constexpr int RK_PAD = RN + 1 + (RN + 1) / E + 8;
 
 struct Prod {  // complex mantissa * 2^e
-  float2 m;
+  C2 m;
   int e;
 };
 __device__ __forceinline__ Prod prod_one() {
   Prod p;
-  p.m = make_float2(1.f, 0.f);
+  p.m = c2((Real)1, (Real)0);
   p.e = 0;
   return p;
 }
 __device__ __forceinline__ void pnorm(Prod &p) {
-  const int de = expo(amax2(p.m));
-  p.m = sc2(p.m, pow2_neg(de));
+  const int de = expo(fmaxf(fabsf((float)p.m.x), fabsf((float)p.m.y)));
+  const Real sc = (Real)pow2_neg(de);
+  p.m = c2(p.m.x * sc, p.m.y * sc);
   p.e += de;
 }
 __device__ __forceinline__ Prod pmul(const Prod &a, const Prod &b) {
   Prod r;
-  r.m = cmul(a.m, b.m);
+  r.m = cmulr(a.m, b.m);
   r.e = a.e + b.e;
   pnorm(r);
   return r;
 }
 template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_r(float old, float src) { return dpp_f<CTRL, ROW_MASK>(old, src); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_r(double old, double src) {  // the two halves of a double move separately
+  const long long o = __double_as_longlong(old), v = __double_as_longlong(src);
+  const int lo = dpp_i<CTRL, ROW_MASK>((int)(o & 0xffffffffLL), (int)(v & 0xffffffffLL));
+  const int hi = dpp_i<CTRL, ROW_MASK>((int)(o >> 32), (int)(v >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ Prod prod_dpp(const Prod &p) {  // identity where the selection has no source lane
   Prod r;
-  r.m.x = dpp_f<CTRL, ROW_MASK>(1.0f, p.m.x);
-  r.m.y = dpp_f<CTRL, ROW_MASK>(0.0f, p.m.y);
+  r.m.x = dpp_r<CTRL, ROW_MASK>((Real)1, p.m.x);
+  r.m.y = dpp_r<CTRL, ROW_MASK>((Real)0, p.m.y);
   r.e = dpp_i<CTRL, ROW_MASK>(0, p.e);
   return r;
+}
+// A product in a segment record: float32 mantissa in floats [at, at+1]; the double variant keeps its mantissa in the
+// 8-byte slots [at2, at2+3] of the record (records are 128-byte aligned).  Exponent as an int in float slot `ate`.
+__device__ __forceinline__ void put_prod(float *info, int at, int at2, int ate, const Prod &p) {
+  if (LONG) {
+    reinterpret_cast<double *>(info + at2)[0] = (double)p.m.x;
+    reinterpret_cast<double *>(info + at2)[1] = (double)p.m.y;
+  } else {
+    info[at] = (float)p.m.x;
+    info[at + 1] = (float)p.m.y;
+  }
+  info[ate] = __int_as_float(p.e);
+}
+__device__ __forceinline__ Prod get_prod(const float *info, int at, int at2, int ate) {
+  Prod p;
+  if (LONG) p.m = c2((Real) reinterpret_cast<const double *>(info + at2)[0], (Real) reinterpret_cast<const double *>(info + at2)[1]);
+  else p.m = c2((Real)info[at], (Real)info[at + 1]);
+  p.e = __float_as_int(info[ate]);
+  return p;
 }
 
 struct SharedR {
@@ -179,27 +229,45 @@ __device__ __forceinline__ float wall_factor(float Ln) {
 }
 __device__ __forceinline__ float wall_factor_short(float Ln) { return fmaf(WALL_A * Ln, Ln * Ln, 1.0f); }
 
-__device__ __forceinline__ float2 ratio_step(float2 al, float k, float2 om, float2 &r, float2 &inv, float &lmin) {
-  r = make_float2(fmaf(-k, om.x, al.x), fmaf(-k, om.y, al.y));
-  const float n = fmaf(r.x, r.x, r.y * r.y);
-  float y = __builtin_amdgcn_rcpf(n);
-  y = fmaf(y, fmaf(-n, y, 1.0f), y);
-  inv = make_float2(r.x * y, -r.y * y);
-  const float Ln = __builtin_amdgcn_logf(n);
+// 1 / n: hardware reciprocal plus one Newton step.  In double the seed is the float32 reciprocal (2e-7), which one
+// step takes to 4e-14.
+__device__ __forceinline__ float rcp_refined(float n, float) {
+  const float y = __builtin_amdgcn_rcpf(n);
+  return fmaf(y, fmaf(-n, y, 1.0f), y);
+}
+__device__ __forceinline__ double rcp_refined(double n, float nf) {
+  const double y = (double)__builtin_amdgcn_rcpf(nf);
+  return fma(y, fma(-n, y, 1.0), y);
+}
+// exp(g) as 1 + (the rest), the sum formed in Real so that in double the factor carries g's full relative precision
+__device__ __forceinline__ Real wall_factor_r(float Ln) {
+  if (!LONG) return (Real)wall_factor(Ln);
+  const float t = Ln * Ln;
+  const float q = t * Ln;
+  return (Real)1 + (Real)(q * fmaf(q, 0.5f * WALL_A * WALL_A, fmaf(t, -WALL_B, WALL_A)));
+}
+
+__device__ __forceinline__ C2 ratio_step(float2 al, float k, C2 om, C2 &r, C2 &inv, float &lmin) {
+  r = c2(rfma(-(Real)k, om.x, (Real)al.x), rfma(-(Real)k, om.y, (Real)al.y));
+  const Real n = rfma(r.x, r.x, r.y * r.y);
+  const float nf = (float)n;
+  const Real y = rcp_refined(n, nf);
+  inv = c2(r.x * y, -r.y * y);
+  const float Ln = __builtin_amdgcn_logf(nf);
   lmin = fminf(lmin, Ln);
-  const float wc = wall_factor(Ln);
-  return make_float2(inv.x * wc, inv.y * wc);
+  const Real wc = wall_factor_r(Ln);
+  return c2(inv.x * wc, inv.y * wc);
 }
 // The same step where only om(r) and r are wanted (phi: the product takes s itself, not its reciprocal).
-__device__ __forceinline__ float2 ratio_step_om(float2 al, float k, float2 om, float2 &r, float &lmin) {
-  r = make_float2(fmaf(-k, om.x, al.x), fmaf(-k, om.y, al.y));
-  const float n = fmaf(r.x, r.x, r.y * r.y);
-  float y = __builtin_amdgcn_rcpf(n);
-  y = fmaf(y, fmaf(-n, y, 1.0f), y);
-  const float Ln = __builtin_amdgcn_logf(n);
+__device__ __forceinline__ C2 ratio_step_om(float2 al, float k, C2 om, C2 &r, float &lmin) {
+  r = c2(rfma(-(Real)k, om.x, (Real)al.x), rfma(-(Real)k, om.y, (Real)al.y));
+  const Real n = rfma(r.x, r.x, r.y * r.y);
+  const float nf = (float)n;
+  const Real y = rcp_refined(n, nf);
+  const float Ln = __builtin_amdgcn_logf(nf);
   lmin = fminf(lmin, Ln);
-  const float yw = y * wall_factor(Ln);
-  return make_float2(r.x * yw, -r.y * yw);
+  const Real yw = y * wall_factor_r(Ln);
+  return c2(r.x * yw, -r.y * yw);
 }
 // Warm-up form: the short clamp factor and no Newton refinement.  Both leave one-signed errors of 1e-9 .. 1e-8, which
 // the steps after them contract; the last warm-up steps are full steps (ratio_step_om) so that what reaches the lane's
@@ -349,7 +417,7 @@ __device__ __forceinline__ unsigned commit_ratio(const RowCfg &cfg, const float 
 // SAVE (MODE 0 only, for the analytic backward): also stores r_j and s_j, and writes G_raw (before the final
 // log-magnitude clamp and the clip; 0 outside 1e-18 <= |G_raw| <= 1e18) instead of G.
 template <typename TIn, bool PHI_EXACT, int MODE, bool SAVE = false>
-__global__ __launch_bounds__(RT, (MODE == 0 && !SAVE) ? BK_RATIO_WAVES : 2) void bk_ratio_forward_kernel(
+__global__ __launch_bounds__(RT, (MODE == 0 && !SAVE && !LONG) ? BK_RATIO_WAVES : 2) void bk_ratio_forward_kernel(
     const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
     const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, float2 *__restrict__ G_,
     float2 *__restrict__ F_, char *__restrict__ ws, int *state, unsigned flags, float fclamp, int S,
@@ -383,19 +451,14 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE) ? BK_RATIO_WAVES : 2) void
   bool bad = false;
   int nscan = 0;
   if (t == 0) {
-    Prod p0 = prod_one();
-    if (MODE == 2) {
-      p0.m = make_float2(info[12], info[13]);
-      p0.e = __float_as_int(info[14]);
-    }
-    sh.carry[0] = p0;
+    sh.carry[0] = MODE == 2 ? get_prod(info, 12, 20, 14) : prod_one();
   }
 
   // Raw inputs of the chunk about to be processed.  One workgroup per row without the saving stores fits 3 waves per
   // SIMD (168 registers) when the loads are issued at the start of the chunk and the CU's other workgroups cover their
   // latency; the other variants hold the next chunk's inputs in registers during the current chunk's arithmetic
   // (2 waves per SIMD).
-  constexpr bool PREFETCH = !(MODE == 0 && !SAVE && BK_RATIO_WAVES >= 3) && BK_RATIO_PREFETCH;
+  constexpr bool PREFETCH = !(MODE == 0 && !SAVE && BK_RATIO_WAVES >= 3) && !LONG && BK_RATIO_PREFETCH;
   float av[RNJ], bv[RNJ], cv[RNJ];
   auto prefetch = [&](int ch) __attribute__((always_inline)) {
     // `full`: the chunk and its halos (and the one extra k) lie inside the row
@@ -419,47 +482,55 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE) ? BK_RATIO_WAVES : 2) void
     const float2 *al_l = sh.u.in.al_s + rpad16(q0);
     const float *k_l = sh.u.in.k_s + rpad16(q0);
     const long i0 = base + (long)seg * E;
-    float2 ir[E];                     // 1 / r_e; then (unless SAVE) the lane-local part of G_raw
-    float2 sv[SAVE ? E : 1];          // s_e and the lane-local part of G_raw as arrays of their own: saving variant only
-    float2 lc[SAVE ? E : 1];
+    C2 ir[E];                         // 1 / r_e; then (unless SAVE) the lane-local part of G_raw
+    C2 sv[SAVE ? E : 1];              // s_e and the lane-local part of G_raw as arrays of their own: saving variant only
+    C2 lc[SAVE ? E : 1];
     // Warm-up: theta over the 16 elements to the left of the lane's own, phi over the 16 to the right, the two
     // independent chains side by side.  Past the end of the row om_phi = 0 (phi_{N+1} = 0: the recurrence starts with
     // s_{N-1} = a'_{N-1}).
 #if BK_RATIO_EXPERIMENT == 1
     // development: no chain arithmetic at all (memory and staging floor of the kernel)
-    float2 wt = make_float2(0.f, 0.f), wp = make_float2(0.f, 0.f), r = wt, inv = wt;
+    C2 wp = c2((Real)0, (Real)0);
     float lmin = 0.0f;
-    const float2 th_west = wt, ph_west = wp, th_fin = wt;
+    const float2 th_west = make_float2(0.f, 0.f), ph_west = th_west, th_fin = th_west;
     Prod run = prod_one();
     int le[E / 4];
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-      ir[j] = al_l[roff(j)];
-      ir[j].x += k_l[roff(j)];
+      ir[j] = to_c2(al_l[roff(j)]);
+      ir[j].x += (Real)k_l[roff(j)];
       le[j >> 2] = 0;
     }
-    (void)r; (void)inv;
 #else
-    float2 wt = make_float2(0.f, 0.f), wp = make_float2(0.f, 0.f), r, inv;
+    // The coarse and short-factor steps run in float32 whatever Real is (their error is contracted away); the last
+    // RH_FULL steps and everything after them in Real.
+    float2 wtf = make_float2(0.f, 0.f), wpf = make_float2(0.f, 0.f);
+    C2 wt, wp, r, inv;
     float lmin = 0.0f;
 #pragma unroll
     for (int j = 0; j < RH; ++j) {
       const int d = E + RH - 1 - j;
       if (j < RH_COARSE) {
-        wt = ratio_step_coarse(al_l[roff(j - RH)], k_l[roff(j - RH)], wt);
-        wp = ratio_step_coarse(al_l[roff(d)], k_l[roff(d + KO)], wp);
+        wtf = ratio_step_coarse(al_l[roff(j - RH)], k_l[roff(j - RH)], wtf);
+        wpf = ratio_step_coarse(al_l[roff(d)], k_l[roff(d + KO)], wpf);
+        if (TAIL && i0 + d >= N) wpf = make_float2(0.f, 0.f);
       } else if (j < RH - RH_FULL) {
-        wt = ratio_step_warm(al_l[roff(j - RH)], k_l[roff(j - RH)], wt);
-        wp = ratio_step_warm(al_l[roff(d)], k_l[roff(d + KO)], wp);
+        wtf = ratio_step_warm(al_l[roff(j - RH)], k_l[roff(j - RH)], wtf);
+        wpf = ratio_step_warm(al_l[roff(d)], k_l[roff(d + KO)], wpf);
+        if (TAIL && i0 + d >= N) wpf = make_float2(0.f, 0.f);
       } else {
+        if (j == RH - RH_FULL) {
+          wt = to_c2(wtf);
+          wp = to_c2(wpf);
+        }
         float lw = 0.0f;  // the warm-up's own small ratios are not the row's
         wt = ratio_step_om(al_l[roff(j - RH)], k_l[roff(j - RH)], wt, r, lw);
         wp = ratio_step_om(al_l[roff(d)], k_l[roff(d + KO)], wp, r, lw);
+        if (TAIL && i0 + d >= N) wp = c2((Real)0, (Real)0);
       }
-      if (TAIL && i0 + d >= N) wp = make_float2(0.f, 0.f);
       BK_SCHED_FENCE(j);
     }
-    const float2 th_west = wt, ph_west = wp;
+    const float2 th_west = to_f2(wt), ph_west = to_f2(wp);
 
     BK_STAMP(4);
     // theta over the lane's own elements, left -> right: keeps 1 / r_e
@@ -469,7 +540,7 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE) ? BK_RATIO_WAVES : 2) void
       ir[j] = inv;
       BK_SCHED_FENCE(j);
     }
-    const float2 th_fin = wt;
+    const float2 th_fin = to_f2(wt);
 
     BK_STAMP(5);
     // phi right -> left with the lane-local products folded in: loc_e = (1/r_e) * prod_{e' > e} s_e' / r_e' replaces
@@ -481,10 +552,10 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE) ? BK_RATIO_WAVES : 2) void
     for (int j = 0; j < E; ++j) {
       const int e = E - 1 - j;
       wp = ratio_step_om(al_l[roff(e)], k_l[roff(e + KO)], wp, r, lmin);
-      if (TAIL && i0 + e >= N) wp = make_float2(0.f, 0.f);
+      if (TAIL && i0 + e >= N) wp = c2((Real)0, (Real)0);
       const bool valid = !TAIL || i0 + e < N;
-      const float2 loc = cmul(ir[e], run.m);
-      if (valid) run.m = cmul(loc, r);
+      const C2 loc = cmulr(ir[e], run.m);
+      if (valid) run.m = cmulr(loc, r);
       if constexpr (SAVE) {
         sv[e] = r;
         lc[e] = loc;
@@ -498,7 +569,7 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE) ? BK_RATIO_WAVES : 2) void
       BK_SCHED_FENCE(j);
     }
 #endif
-    const float2 ph_fin = wp;
+    const float2 ph_fin = to_f2(wp);
 
     BK_STAMP(6);
     bad |= !(lmin >= WALL_LN_MIN);  // a ratio below 1e-2 in magnitude: outside the clamp factor's series
@@ -512,12 +583,13 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE) ? BK_RATIO_WAVES : 2) void
         if (pass == 0) {
 #pragma unroll
           for (int e = 0; e < E; ++e) {  // r = 1 / (1/r)
-            const float y = 1.0f / fmaf(ir[e].x, ir[e].x, ir[e].y * ir[e].y);
-            slot_sv[e] = make_float2(ir[e].x * y, -ir[e].y * y);
+            const float2 q = to_f2(ir[e]);
+            const float y = 1.0f / fmaf(q.x, q.x, q.y * q.y);
+            slot_sv[e] = make_float2(q.x * y, -q.y * y);
           }
         } else {
 #pragma unroll
-          for (int e = 0; e < E; ++e) slot_sv[e] = sv[e];
+          for (int e = 0; e < E; ++e) slot_sv[e] = to_f2(sv[e]);
         }
         __syncthreads();
         float2 *__restrict__ dst = (pass == 0 ? save_r_ : save_s_) + row * N + base;
@@ -595,8 +667,8 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE) ? BK_RATIO_WAVES : 2) void
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       float2 P;
-      if constexpr (SAVE) P = cmul(lc[e], Fin.m);
-      else P = cmul(ir[e], Fin.m);
+      if constexpr (SAVE) P = to_f2(cmulr(lc[e], Fin.m));
+      else P = to_f2(cmulr(ir[e], Fin.m));
       const int Ee = Fin.e + le[e >> 2];
       const float Ef = (float)Ee;
       const float n = fmaf(P.x, P.x, P.y * P.y);
@@ -617,8 +689,8 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE) ? BK_RATIO_WAVES : 2) void
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         float2 P;
-        if constexpr (SAVE) P = cmul(lc[e], Fin.m);
-        else P = cmul(ir[e], Fin.m);
+        if constexpr (SAVE) P = to_f2(cmulr(lc[e], Fin.m));
+        else P = to_f2(cmulr(ir[e], Fin.m));
         const int Ee = Fin.e + le[e >> 2];
         const float n = fmaf(P.x, P.x, P.y * P.y);
         const float L = LN2_HALF * fmaf(2.0f, (float)Ee, __builtin_amdgcn_logf(n));  // ln |G_raw|
@@ -685,10 +757,7 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE) ? BK_RATIO_WAVES : 2) void
       rowflag[row] = any_bad;
       if (any_bad) __hip_atomic_store(&state[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (MODE == 1) {
-      const Prod tot = sh.carry[nscan & 1];  // started from one: the segment's own product
-      info[0] = tot.m.x;
-      info[1] = tot.m.y;
-      info[2] = __int_as_float(tot.e);
+      put_prod(info, 0, 16, 2, sh.carry[nscan & 1]);  // started from one: the segment's own product
       info[3] = any_bad ? 1.0f : 0.0f;
     } else if (any_bad) {
       atomicOr(&rowflag[row], 1);
@@ -716,8 +785,7 @@ __global__ __launch_bounds__(64) void bk_ratio_combine_kernel(long B, long N, ch
     Prod q = prod_one();
     if (idx < S) {
       const float *me = info + sg * SEG_INFO;
-      q.m = make_float2(me[0], me[1]);
-      q.e = __float_as_int(me[2]);
+      q = get_prod(me, 0, 16, 2);
       bad |= me[3] != 0.0f;
       if (sg < S - 1) {
         const float *rt = me + SEG_INFO;  // the segment to the right
@@ -741,9 +809,7 @@ __global__ __launch_bounds__(64) void bk_ratio_combine_kernel(long B, long N, ch
     ex = pmul(carry, ex);
     if (idx < S) {
       float *me = info + sg * SEG_INFO;
-      me[12] = ex.m.x;
-      me[13] = ex.m.y;
-      me[14] = __int_as_float(ex.e);
+      put_prod(me, 12, 20, 14, ex);
     }
     Prod last;
     last.m.x = __shfl(q.m.x, 63);
@@ -774,12 +840,20 @@ void ratio_launch(int mode, int save, const void *a, long lda, const void *b, lo
   if (mode == 1) BK_RATIO(1, false, B * S);
   else if (mode == 2) BK_RATIO(2, false, B * S);
   else if (!save) BK_RATIO(0, false, B);
+#if !BK_RATIO_LONG
   else if (std::is_same<TIn, float>::value) BK_RATIO(0, true, B);  // the saving variant exists for float32 operands
+#endif
 #undef BK_RATIO
 }
 }  // namespace
 
-extern "C" void bkcore_internal_ratio_forward(int in_dtype, int phi_exact, int mode, int save, const void *a,
+#if BK_RATIO_LONG
+#define BK_RATIO_ENTRY(name) name##_long
+#else
+#define BK_RATIO_ENTRY(name) name
+#endif
+
+extern "C" void BK_RATIO_ENTRY(bkcore_internal_ratio_forward)(int in_dtype, int phi_exact, int mode, int save, const void *a,
                                               int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
                                               const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G,
                                               float *features, void *ws, void *state, unsigned flags,
@@ -808,9 +882,11 @@ extern "C" void bkcore_internal_ratio_forward(int in_dtype, int phi_exact, int m
 #undef BK_DISPATCH
 }
 
+#if !BK_RATIO_LONG
 extern "C" int bkcore_internal_ratio_chunk(void) { return RCHUNK; }
+#endif
 
-extern "C" void bkcore_internal_ratio_combine(int64_t B, int64_t N, void *ws, void *state, int S,
+extern "C" void BK_RATIO_ENTRY(bkcore_internal_ratio_combine)(int64_t B, int64_t N, void *ws, void *state, int S,
                                               void *stream) {
   hipLaunchKernelGGL(bk_ratio_combine_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, (long)B, (long)N,
                      (char *)ws, (int *)state, S);

@@ -9,5 +9,5 @@ a = -2.0 + 0.5 * torch.randn(B, N, generator=g, device="cuda")
 b = torch.ones(B, N - 1, device="cuda"); c = torch.ones(B, N - 1, device="cuda")
 z = torch.tensor(1j, dtype=torch.complex64, device="cuda")
 for _ in range(int(os.environ.get("BK_REPS", 3))):
-    bkcore.bk_forward(a, b, c, z)
+    bkcore.bk_forward(a, b, c, z, share_storage=os.environ.get('BK_SHARE', '1') == '1')
 torch.cuda.synchronize()
