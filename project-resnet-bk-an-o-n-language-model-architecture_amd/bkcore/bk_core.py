@@ -88,6 +88,14 @@ def _rows(x: torch.Tensor, n_inner: int, name: str):
     return x, x.data_ptr(), ld
 
 
+def _check_batch(B: int, b: torch.Tensor, c: torch.Tensor):
+    """b and c hold one row per row of a, or a single row that is broadcast (leading dimension 0); anything else
+    would make the kernels read past the operand (the reference's vmap raises on such shapes too)."""
+    for name, x in (("h0_super", b), ("h0_sub", c)):
+        if x.dim() == 2 and x.shape[0] not in (1, B):
+            raise ValueError(f"bkcore: {name} has {x.shape[0]} rows for a batch of {B} (expected {B} or 1)")
+
+
 def _prep_inputs(a, b, c):
     if a.is_complex() or b.is_complex() or c.is_complex():
         raise TypeError("bkcore: complex a/b/c are not supported by the HIP kernels (real dtypes only)")
@@ -144,6 +152,7 @@ def bk_forward(a, b, c, z, raw: bool = False, phi_exact: bool = False, want_feat
         feats_out = feats
     if B == 0 or N == 0:
         return feats_out, G
+    _check_batch(B, b, c)
     a, pa, lda = _rows(a, N, "a")
     b, pb, ldb = _rows(b, nb, "b")
     c, pc, ldc = _rows(c, nb, "c")
@@ -299,6 +308,7 @@ def bk_backward_analytic(a, b, c, z, grad_features, grad_G, phi_exact: bool = Fa
     gc = torch.empty((B, nb), dtype=torch.float32, device=a.device) if want_bc else None
     if B == 0 or N == 0:
         return ga, gb, gc
+    _check_batch(B, b, c)
     a, pa, lda = _rows(a, N, "a")
     b, pb, ldb = _rows(b, nb, "b")
     c, pc, ldc = _rows(c, nb, "c")

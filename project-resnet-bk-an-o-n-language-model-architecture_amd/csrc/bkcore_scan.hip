@@ -143,7 +143,11 @@ __global__ __launch_bounds__(ST) void bk_cumsum_row_kernel(const float *__restri
     const float incl = wave_inclusive_scan(v[3]);
     if (lane == 63) wtot[buf][wave] = incl;
     __syncthreads();
-    float before = carry + (incl - v[3]), all = 0.0f;
+    // exclusive prefix of the lane inside its wave: the inclusive scan moved one lane up (0 into lane 0), not
+    // incl - v[3], which is inf - inf = NaN once the lane's own group holds an infinity and loses the prefix by
+    // cancellation when the group is much larger than what came before it
+    const float excl = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(incl), 0x138, 0xF, 0xF, false));
+    float before = carry + excl, all = 0.0f;
 #pragma unroll
     for (int w = 0; w < ST / 64; ++w) {
       const float tw = wtot[buf][w];

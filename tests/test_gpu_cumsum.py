@@ -58,3 +58,31 @@ def test_cumsum_integers_are_exact_and_gradient_is_reverse_scan():
     yb = bkcore.fused_associative_scan(xb, dim=1)
     assert yb.dtype == torch.bfloat16
     assert float((yb.float() - torch.cumsum(xb.float(), 1)).abs().max()) <= 0.1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reverse", [False, True])
+def test_cumsum_last_dim_infinity_and_mixed_magnitudes(reverse):
+    """Row kernel: an infinity poisons only the positions from it onwards (as torch.cumsum), and a huge group does not
+    cancel the prefix that came before it."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import bkcore
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 3000, generator=g)
+    x[0, 1501] = float("inf")
+    x[1, 700] = 3.0e7          # partial sums before it are O(30): lost if the prefix were formed by subtraction
+    x[1, 701] = -3.0e7
+    xd = x.double()
+    want = torch.flip(torch.cumsum(torch.flip(xd, [1]), 1), [1]) if reverse else torch.cumsum(xd, 1)
+    got = bkcore.fused_associative_scan(x.cuda(), dim=1, reverse=reverse).cpu().double()
+    fin = torch.isfinite(want)
+    assert torch.equal(torch.isfinite(got), fin)
+    assert torch.equal(got[~fin], want[~fin])
+    # row 1 away from the two huge entries: float32 accuracy of an O(sqrt(L)) running sum, a few units at 3e7's ulp
+    # only where the huge entry is part of the sum
+    sel = torch.ones_like(fin)
+    sel[1, 700:702] = False
+    assert float((got - want)[fin & sel].abs().max()) <= 4.0
+    sel[1] = False
+    assert float((got - want)[fin & sel].abs().max()) <= 1e-3

@@ -344,3 +344,63 @@ def test_cpu_tensors_fail_loudly(bk):
     a = torch.zeros(1, 8)
     with pytest.raises(RuntimeError, match="ROCm device"):
         bk.vmapped_get_diag(a, a[:, :-1], a[:, :-1], 1j)
+
+
+def test_batch_rows_of_off_diagonals_are_validated(bk):
+    """h0_super / h0_sub with a row count that is neither the batch nor 1 would be read out of bounds."""
+    a = torch.zeros(4, 16, device="cuda")
+    good = torch.ones(4, 15, device="cuda")
+    for bad in (torch.ones(2, 15, device="cuda"), torch.ones(3, 15, device="cuda")):
+        with pytest.raises(ValueError, match="rows for a batch"):
+            bk.BKCoreFunction.apply(a, bad, good, 1j)
+        with pytest.raises(ValueError, match="rows for a batch"):
+            bk.bk_backward_analytic(a, good, bad, 1j, torch.zeros(4, 16, 2, device="cuda"), None)
+    bk.BKCoreFunction.apply(a - 2.0, good[:1], good[:1].expand(4, -1), 1j)     # one row and expand() are fine
+
+
+def test_config3_exact_shape(bk, coracle):
+    """BASELINE configs[2] at its own shape, B = 16 rows of N = 2^20 (rows cut into segments, double-precision chains):
+    two rows against the oracle, no row recomputed, bitwise determinism."""
+    from bkcore import bk_core
+    B, N = 16, 1 << 20
+    g = torch.Generator(device="cuda").manual_seed(2020)
+    a = -2.0 + 0.5 * torch.randn(B, N, generator=g, device="cuda")
+    b = torch.ones(B, N - 1, device="cuda")
+    c = torch.ones(B, N - 1, device="cuda")
+    z = torch.tensor(1j, dtype=torch.complex64, device="cuda")
+    bk_core._DEBUG["keep_ws"] = True
+    try:
+        feats, G = bk.BKCoreFunction.apply(a, b, c, z)
+        torch.cuda.synchronize()
+        assert bk_core.rows_recomputed() == 0
+    finally:
+        bk_core._DEBUG["keep_ws"] = False
+        bk_core._DEBUG["last_ws"] = None
+    rows = [0, 15]
+    ref = coracle.forward_f32(a[rows].cpu().numpy(), b[rows].cpu().numpy(), c[rows].cpu().numpy(), 1j)[1]
+    assert max_rel_err(G[rows].cpu().numpy(), ref) <= TOL
+    assert torch.equal(torch.view_as_real(G), feats)
+    _, G2 = bk.BKCoreFunction.apply(a, b, c, z)
+    assert torch.equal(torch.view_as_real(G2), torch.view_as_real(G))
+
+
+def test_config4_rows_on_one_gpu(bk, coracle):
+    """BASELINE configs[3]'s whole batch, B = 8192 rows of N = 32768, on one GPU: a row subset against the oracle,
+    features == G, and the backward on the same rows."""
+    B, N = 8192, 32768
+    g = torch.Generator(device="cuda").manual_seed(4040)
+    a = -2.0 + 0.5 * torch.randn(B, N, generator=g, device="cuda")
+    bc = torch.ones(1, N - 1, device="cuda").expand(B, -1)      # stride-0 batch dimension, as the layer's buffers
+    z = torch.tensor(1j, dtype=torch.complex64, device="cuda")
+    feats, G = bk.BKCoreFunction.apply(a, bc, bc, z)
+    rows = [0, 4095, 8191]
+    ones = np.ones((len(rows), N - 1), np.float32)
+    ref = coracle.forward_f32(a[rows].cpu().numpy(), ones, ones, 1j)[1]
+    assert max_rel_err(G[rows].cpu().numpy(), ref) <= TOL
+    assert torch.equal(torch.view_as_real(G), feats)
+    gf = torch.randn(len(rows), N, 2, generator=g, device="cuda")
+    grad = bk.bk_backward_reference(G[rows], gf, None, 0.5)
+    gref = coracle.backward_ref(G[rows].cpu().numpy(), gf.cpu().numpy(), None, 0.5)
+    np.testing.assert_allclose(grad.cpu().numpy(), gref, rtol=1e-4, atol=1e-5)
+    del feats, G, a
+    torch.cuda.empty_cache()
