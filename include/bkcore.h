@@ -111,11 +111,15 @@ int bkcore_backward_ref(const float *G, const float *grad_features, const float 
  * grad_features: B*N*2 floats or NULL; grad_G: B*N complex64 or NULL.
  * grad_a: B*N floats.  grad_b, grad_c: B*(N-1) floats each, or both NULL.
  * flags: BKCORE_FLAG_PHI_EXACT or 0, as given to the forward.
- * workspace: at least bkcore_backward_analytic_workspace_bytes(B, N) bytes (the forward is re-run inside this call
- *    to obtain the theta / phi ratios; nothing from the caller's forward is needed); state: as in bkcore_forward.
+ * G: the B*N complex64 that bkcore_forward wrote for these inputs and flags (contiguous), or NULL to have it computed
+ *    here.  The theta / phi ratios are recomputed inside the two sweeps of this call from a, b, c; only G is read
+ *    from the forward.
+ * workspace: at least bkcore_backward_analytic_workspace_bytes(B, N) bytes; state: as in bkcore_forward (rows whose
+ *    in-kernel checks fail are redone by a slower three-pass path in the same call; with state == NULL every row
+ *    takes that path).
  */
 int bkcore_backward_analytic(const float *a, int64_t lda, const float *b, int64_t ldb, const float *c, int64_t ldc,
-                             const float *z_dev, float z_re, float z_im, int64_t B, int64_t N,
+                             const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, const float *G,
                              const float *grad_features, const float *grad_G, float *grad_a, float *grad_b,
                              float *grad_c, void *workspace, size_t workspace_bytes, void *state, unsigned flags,
                              void *stream);

@@ -14,7 +14,7 @@ FLAG_RAW = 1
 FLAG_PHI_EXACT = 2
 FLAG_SCAN_PATH = 4
 STATE_BYTES = 64
-ABI_VERSION = 9
+ABI_VERSION = 10
 EINVAL, ETOOLONG, ELAUNCH, EWORKSPACE, ETOOBIG = -1, -2, -3, -4, -5
 NOALLOC_MAX_WORKSPACE = 8 << 20
 
@@ -50,7 +50,7 @@ def load():
     L.bkcore_forward.restype = i32
     L.bkcore_backward_ref.argtypes = [vp, vp, vp, f32, i64, vp, vp]
     L.bkcore_backward_ref.restype = i32
-    L.bkcore_backward_analytic.argtypes = [vp, i64, vp, i64, vp, i64, vp, f32, f32, i64, i64, vp, vp, vp, vp, vp,
+    L.bkcore_backward_analytic.argtypes = [vp, i64, vp, i64, vp, i64, vp, f32, f32, i64, i64, vp, vp, vp, vp, vp, vp,
                                            vp, ctypes.c_size_t, vp, ctypes.c_uint, vp]
     L.bkcore_backward_analytic.restype = i32
     L.bkcore_backward_analytic_workspace_bytes.argtypes = [i64, i64]

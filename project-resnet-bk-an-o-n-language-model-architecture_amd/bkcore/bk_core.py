@@ -293,8 +293,9 @@ def sanitise_inputs(he_diag, h0_super, h0_sub):
     return a, b, c, pa, pb, pc
 
 
-def bk_backward_analytic(a, b, c, z, grad_features, grad_G, phi_exact: bool = False, want_bc: bool = True):
-    """Launch the analytic backward.  a (B,N), b/c (B,N-1): float32, already sanitised.
+def bk_backward_analytic(a, b, c, z, grad_features, grad_G, phi_exact: bool = False, want_bc: bool = True, G=None):
+    """Launch the analytic backward.  a (B,N), b/c (B,N-1): float32, already sanitised.  G: the (B,N) complex64 the
+    forward returned for these operands (None: it is computed again inside the call).
     Returns (grad_a, grad_b|None, grad_c|None), float32."""
     L = _lib.load()
     if a.dtype != torch.float32 or b.dtype != torch.float32 or c.dtype != torch.float32:
@@ -322,6 +323,11 @@ def bk_backward_analytic(a, b, c, z, grad_features, grad_G, phi_exact: bool = Fa
         gg = grad_G.to(torch.complex64).contiguous()
         if tuple(gg.shape) != (B, N):
             raise ValueError("bkcore: grad_G must have shape (B, N)")
+    gsaved = None
+    if G is not None:
+        if G.dtype != torch.complex64 or tuple(G.shape) != (B, N) or G.device != a.device:
+            raise ValueError("bkcore: G must be the (B, N) complex64 output of the forward, on the operands' device")
+        gsaved = G.contiguous()
     with _on_device(a.device):
         stream = torch.cuda.current_stream().cuda_stream
         zkeep, pz, zre, zim = _prep_z(z, a.device)
@@ -329,6 +335,7 @@ def bk_backward_analytic(a, b, c, z, grad_features, grad_G, phi_exact: bool = Fa
         ws_bytes = int(L.bkcore_backward_analytic_workspace_bytes(B, N))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
         rc = L.bkcore_backward_analytic(pa, lda, pb if nb else None, ldb, pc if nb else None, ldc, pz, zre, zim, B, N,
+                                        gsaved.data_ptr() if gsaved is not None else None,
                                         gf.data_ptr() if gf is not None else None,
                                         gg.data_ptr() if gg is not None else None, ga.data_ptr(),
                                         gb.data_ptr() if gb is not None and nb else None,
@@ -390,7 +397,7 @@ class BKCoreFunction(torch.autograd.Function):
             ctx.bk_phi_exact = BKCoreFunction.PHI_K_INDEX == "exact"
             ctx.bk_z = z.detach() if torch.is_tensor(z) else z
             ctx.bk_shapes = (he_diag.shape, h0_super.shape, h0_sub.shape)
-            ctx.save_for_backward(he_diag, h0_super, h0_sub)   # the backward re-runs the forward
+            ctx.save_for_backward(he_diag, h0_super, h0_sub, G)   # the ratios are recomputed from the operands
         elif ctx.bk_mode == "reference":
             ctx.save_for_backward(G)                   # only G is saved (bk_core.py:293)
         else:
@@ -409,7 +416,7 @@ class BKCoreFunction(torch.autograd.Function):
             warnings.warn(msg, RuntimeWarning)
             logger.warning(msg)
         if ctx.bk_mode == "analytic":
-            a, b, c = ctx.saved_tensors
+            a, b, c, G = ctx.saved_tensors
             n = a.shape[-1]
             nb = max(n - 1, 0)
             rows = a.numel() // max(n, 1)
@@ -418,7 +425,7 @@ class BKCoreFunction(torch.autograd.Function):
             gg = grad_G_ii.reshape(-1, n) if grad_G_ii is not None else None
             want_bc = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
             ga, gb, gc = bk_backward_analytic(a2, b2, c2, ctx.bk_z, gf, gg,
-                                              phi_exact=ctx.bk_phi_exact, want_bc=want_bc)
+                                              phi_exact=ctx.bk_phi_exact, want_bc=want_bc, G=G.reshape(rows, n))
             sa, sb, sc = ctx.bk_shapes
             ga = (ga * pa).reshape(sa) if ctx.needs_input_grad[0] else None
             gb_o = (gb * pb).reshape(sb) if ctx.needs_input_grad[1] else None

@@ -265,10 +265,13 @@ __global__ __launch_bounds__(T) void bk_adjoint_phi_kernel(
     const float *__restrict__ a_, long lda, const float *__restrict__ b_, long ldb, const float *__restrict__ c_,
     long ldc, const float *__restrict__ z_dev, float z_re, float z_im, long N, const float *__restrict__ Graw_,
     const float *__restrict__ gf_, const float *__restrict__ gG_, const float *__restrict__ s_,
-    float *__restrict__ P_, float *__restrict__ ga_, float *__restrict__ gk_) {
+    float *__restrict__ P_, float *__restrict__ ga_, float *__restrict__ gk_, const int *__restrict__ row_filter,
+    const int *gate) {
   __shared__ SharedAff sha;
   __shared__ SharedSum shs;
   const long row = blockIdx.x;
+  if (gate && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+  if (row_filter && row_filter[row] == 0) return;
   const float *a = a_ + row * lda, *b = b_ + row * ldb, *c = c_ + row * ldc;
   const float *Graw = Graw_ + row * N * 2;
   const float *gf = gf_ ? gf_ + row * N * 2 : nullptr, *gG = gG_ ? gG_ + row * N * 2 : nullptr;
@@ -365,9 +368,12 @@ template <int OFF>
 __global__ __launch_bounds__(T) void bk_adjoint_theta_kernel(
     const float *__restrict__ a_, long lda, const float *__restrict__ b_, long ldb, const float *__restrict__ c_,
     long ldc, const float *__restrict__ z_dev, float z_re, float z_im, long N, const float *__restrict__ r_,
-    const float *__restrict__ P_, float *__restrict__ ga_, float *__restrict__ gb_, float *__restrict__ gc_) {
+    const float *__restrict__ P_, float *__restrict__ ga_, float *__restrict__ gb_, float *__restrict__ gc_,
+    const int *__restrict__ row_filter, const int *gate) {
   __shared__ SharedAff sha;
   const long row = blockIdx.x;
+  if (gate && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+  if (row_filter && row_filter[row] == 0) return;
   const float *a = a_ + row * lda, *b = b_ + row * ldb, *c = c_ + row * ldc;
   const float *rv = r_ + row * N * 2, *P = P_ + row * N * 2;
   float *ga = ga_ + row * N;
@@ -431,18 +437,377 @@ __global__ __launch_bounds__(T) void bk_adjoint_theta_kernel(
   }
 }
 
+
+// ==== two sweeps with the ratios recomputed in the kernel ==========================================================
+// Nothing but G is kept from the forward (as in the reference, bk_core.py:293).  The cotangent of G_raw follows from G
+// itself: with X = conj(gbar) G,  q = X - tanh^2(L_raw/88) Re X  and  tanh(L_raw/88) = ln|G| / 88  (the final clamp is
+// ln|G| = 88 tanh(L_raw/88)); a clipped element (|G| = 50) passes only Im X; G = 0 passes nothing.  The ratios r and s
+// are recomputed from a, b, c exactly as the forward does: wherever the ratio maps contract, a lane gets the ratio
+// entering its 8 elements by running the map over the 16 elements before them (after them, for s), verified against
+// the neighbouring lane's own value.  So each sweep reads a, b, c, G and the cotangent once:
+//   bk_adjoint_sweep_phi   : chunks left -> right : s, P (prefix sums of q), mu; writes the phi part of grad_a and of
+//                            grad_k into the output buffers, and the row's total sum of q
+//   bk_adjoint_sweep_theta : chunks right -> left : r, P = total - suffix sums, lam; adds the theta parts, writes
+//                            grad_a, grad_b, grad_c
+// A row with a failed check is flagged (rowbad[row], state[5]) and recomputed by the three-pass path above, whose
+// launches follow and skip every other row.
+constexpr int WH = 16;                      // warm-up steps = halo staged on both sides of a chunk
+constexpr int SN = CHUNK + 2 * WH;          // staged elements per chunk (k: one more)
+constexpr int SPAD = SN + 1 + (SN + 1) / EB + 8;
+struct SharedStage {
+  float2 al_s[SPAD];   // regularised diagonal of elements base - WH .. base + CHUNK + WH - 1, slot q at q + q / EB
+  float k_s[SPAD];     // k_{i-1} for the same elements, plus one more
+};
+__device__ __forceinline__ constexpr int spad(int q) { return q + q / EB; }
+
+constexpr float WALL_C = 0.69314718055994531f / 176.0f;
+constexpr float WALL_A = 88.0f * WALL_C * WALL_C * WALL_C / 3.0f;
+constexpr float WALL_B = 176.0f * WALL_C * WALL_C * WALL_C * WALL_C * WALL_C / 15.0f;
+
+__device__ __forceinline__ float2 reg_diag(float a, float2 z) {  // reg(a - z), bk_core.py:78-94
+  const float xr = a - z.x, xi = -z.y;
+  const float n = fmaf(xr, xr, xi * xi);
+  float f = fmaf(1e-3f, __builtin_amdgcn_rsqf(n), 1.0f);
+  float add = 0.0f;
+  if (!(n >= 1e-24f)) { f = 1.0f; add = 1e-3f; }
+  return make_float2(fmaf(xr, f, add), xi * f);
+}
+
+__device__ __forceinline__ void stage_rows(const float *__restrict__ a, const float *__restrict__ b,
+                                           const float *__restrict__ c, long base, long N, float2 z, SharedStage &sh) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < (SN + 1 + T - 1) / T; ++j) {
+    const int q = t + j * T;
+    if (q <= SN) {
+      const long i = base - WH + q;
+      const float av = (i >= 0 && i < N) ? a[i] : 1.0f;
+      const float kv = (i >= 1 && i <= N - 1) ? b[i - 1] * c[i - 1] : 0.0f;
+      sh.k_s[spad(q)] = kv;
+      if (q < SN) sh.al_s[spad(q)] = reg_diag(av, z);
+    }
+  }
+}
+
+// Steps of the ratio map r = al - k om, returning om(r) = exp(g(-ln|r|)) / r.  Coarse: no clamp factor.
+__device__ __forceinline__ float2 om_coarse(float2 al, float k, float2 om) {
+  const float2 r = make_float2(fmaf(-k, om.x, al.x), fmaf(-k, om.y, al.y));
+  const float y = __builtin_amdgcn_rcpf(fmaf(r.x, r.x, r.y * r.y));
+  return make_float2(r.x * y, -r.y * y);
+}
+__device__ __forceinline__ float2 om_full(float2 al, float k, float2 om, float2 &inv, float &tau, float &lmin) {
+  const float2 r = make_float2(fmaf(-k, om.x, al.x), fmaf(-k, om.y, al.y));
+  const float n = fmaf(r.x, r.x, r.y * r.y);
+  float y = __builtin_amdgcn_rcpf(n);
+  y = fmaf(y, fmaf(-n, y, 1.0f), y);
+  inv = make_float2(r.x * y, -r.y * y);
+  const float Ln = __builtin_amdgcn_logf(n);  // log2 |r|^2: ln|r| / 88 = WALL_C Ln
+  lmin = fminf(lmin, Ln);
+  const float t2 = Ln * Ln, q3 = t2 * Ln;
+  const float wc = fmaf(q3, fmaf(q3, 0.5f * WALL_A * WALL_A, fmaf(t2, -WALL_B, WALL_A)), 1.0f);
+  const float u2 = WALL_C * WALL_C * t2;       // tanh^2(u) = u^2 (1 - 2u^2/3 ...)
+  tau = u2 * fmaf(u2, -2.0f / 3.0f, 1.0f);
+  return make_float2(inv.x * wc, inv.y * wc);
+}
+__device__ __forceinline__ bool om_differs(float2 p, float2 q) {  // |p - q| > 2e-5 |q|, true for anything not a number
+  const float dx = p.x - q.x, dy = p.y - q.y;
+  return !(fmaf(dx, dx, dy * dy) <= 4.0e-10f * fmaf(q.x, q.x, q.y * q.y));
+}
+
+// q = X - tanh^2(L_raw / 88) Re X for the saved output G and its cotangent gbar (see above)
+__device__ __forceinline__ float2 cot_q_saved(float2 G, float2 gbar) {
+  const float m2 = fmaf(G.x, G.x, G.y * G.y);
+  if (!(m2 > 0.0f)) return make_float2(0.f, 0.f);
+  const float2 X = make_float2(fmaf(gbar.x, G.x, gbar.y * G.y), fmaf(gbar.x, G.y, -gbar.y * G.x));  // conj(gbar) G
+  if (m2 > 2499.99f) return make_float2(0.0f, X.y);
+  const float th = __builtin_amdgcn_logf(m2) * (0.5f * 0.69314718055994531f / 88.0f);  // ln|G| / 88
+  return make_float2(X.x - th * th * X.x, X.y);
+}
+
+struct SharedSweep {
+  SharedStage st;
+  SharedAff aff;
+  SharedSum sum;
+  float2 wedge[2][WAVES];   // last lane of each wave: its warm-up estimate, for the first lane of the next wave
+  float2 edge[2];           // the same from the last lane of the chunk processed before
+};
+
+// Loads the lane's block of G and of the cotangent(s) and forms q for its EB elements (0 outside the row).
+__device__ __forceinline__ void lane_q(const float *__restrict__ G, const float *__restrict__ gf,
+                                       const float *__restrict__ gG, long first, long N, float (&q)[2 * EB]) {
+  float Gv[2 * EB], gv[2 * EB];
+  load_block<2 * EB>(G, 2 * first, 0, 2 * N, 0.0f, Gv);
+  if (gf) {
+    load_block<2 * EB>(gf, 2 * first, 0, 2 * N, 0.0f, gv);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 2 * EB; ++e) gv[e] = 0.0f;
+  }
+  if (gG) {
+    float hv[2 * EB];
+    load_block<2 * EB>(gG, 2 * first, 0, 2 * N, 0.0f, hv);
+#pragma unroll
+    for (int e = 0; e < 2 * EB; ++e) gv[e] += hv[e];
+  }
+#pragma unroll
+  for (int e = 0; e < EB; ++e) {
+    // a cotangent that is not a number counts as 0, as in the reference's backward (bk_core.py:321-325)
+    const float gx = fabsf(gv[2 * e]) <= 3.0e38f ? gv[2 * e] : 0.0f;
+    const float gy = fabsf(gv[2 * e + 1]) <= 3.0e38f ? gv[2 * e + 1] : 0.0f;
+    const float2 qq = cot_q_saved(make_float2(Gv[2 * e], Gv[2 * e + 1]), make_float2(gx, gy));
+    q[2 * e] = qq.x;
+    q[2 * e + 1] = qq.y;
+  }
+}
+
+template <int OFF>  // kphi_m = k_{m-OFF}
+__global__ __launch_bounds__(T) void bk_adjoint_sweep_phi(
+    const float *__restrict__ a_, long lda, const float *__restrict__ b_, long ldb, const float *__restrict__ c_,
+    long ldc, const float *__restrict__ z_dev, float z_re, float z_im, long N, const float *__restrict__ G_,
+    const float *__restrict__ gf_, const float *__restrict__ gG_, float *__restrict__ ga_, float *__restrict__ gk_,
+    float2 *__restrict__ qtot, int *__restrict__ rowbad, int *state) {
+  __shared__ SharedSweep sh;
+  const long row = blockIdx.x;
+  const float *a = a_ + row * lda;
+  const float *b = N >= 2 ? b_ + row * ldb : a, *c = N >= 2 ? c_ + row * ldc : a;
+  const float *G = G_ + row * N * 2;
+  const float *gf = gf_ ? gf_ + row * N * 2 : nullptr, *gG = gG_ ? gG_ + row * N * 2 : nullptr;
+  float *ga = ga_ + row * N;
+  float *gk = gk_ ? gk_ + row * (N - 1) : nullptr;
+  const float2 z = z_dev ? make_float2(z_dev[0], z_dev[1]) : make_float2(z_re, z_im);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int nch = (int)((N + CHUNK - 1) / CHUNK);
+  int nsum = 0, naff = 0;
+  bool bad = false;
+  if (t == 0) {
+    sh.aff.carry[0] = make_float2(0.f, 0.f);
+    sh.sum.carry[0] = make_float2(0.f, 0.f);
+  }
+  for (int ch = 0; ch < nch; ++ch) {
+    const long base = (long)ch * CHUNK;
+    const long first = base + (long)t * EB;
+    __syncthreads();  // the previous chunk's chains have read the staging area
+    stage_rows(a, b, c, base, N, z, sh.st);
+    __syncthreads();
+    const float2 *al_l = sh.st.al_s + spad(WH + t * EB);
+    const float *k_l = sh.st.k_s + spad(WH + t * EB);   // slot of element e holds k_{e-1}
+    // phi: warm-up over the 16 elements to the right of the lane's own (past the end of the row om = 0: the
+    // recurrence starts with s_{N-1} = a'_{N-1}), then the lane's own, right -> left
+    float2 om = make_float2(0.f, 0.f), inv[EB], wv[EB];
+    float tau[EB], lmin = 0.0f, ldummy = 0.0f;
+#pragma unroll
+    for (int j = 0; j < WH; ++j) {
+      const int d = EB + WH - 1 - j;
+      float2 iv;
+      float tv;
+      if (j < WH / 2) om = om_coarse(al_l[d + d / EB], k_l[(d + 1 - OFF) + (d + 1 - OFF) / EB], om);
+      else om = om_full(al_l[d + d / EB], k_l[(d + 1 - OFF) + (d + 1 - OFF) / EB], om, iv, tv, ldummy);
+      if (first + d >= N) om = make_float2(0.f, 0.f);
+    }
+    const float2 west = om;
+#pragma unroll
+    for (int j = 0; j < EB; ++j) {
+      const int e = EB - 1 - j;
+      const int ke = e + 1 - OFF;                        // slot offset holding kphi_e = k_{e-OFF}
+      om = om_full(al_l[e], k_l[ke + ke / EB], om, inv[e], tau[e], lmin);
+      if (first + e >= N) om = make_float2(0.f, 0.f);
+      wv[e] = om;
+    }
+    // the left neighbour's warm-up ran over this lane's elements: both must agree on om at the lane's first element
+    {
+      const int buf = ch & 1;
+      if (lane == 63) sh.wedge[buf][wave] = west;
+      if (t == T - 1) sh.edge[buf] = west;
+      float2 nb = make_float2(dpp_f<0x138, 0xF>(0.f, west.x), dpp_f<0x138, 0xF>(0.f, west.y));
+      __syncthreads();
+      if (lane == 0) nb = wave > 0 ? sh.wedge[buf][wave - 1] : sh.edge[buf ^ 1];
+      if ((t > 0 || ch > 0) && first < N) bad |= om_differs(nb, om);
+      bad |= !(lmin >= -13.3f);
+    }
+    float q[2 * EB];
+    lane_q(G, gf, gG, first, N, q);
+    float2 sum = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int e = 0; e < EB; ++e) sum = cadd(sum, make_float2(q[2 * e], q[2 * e + 1]));
+    float2 Prun = block_exclusive_sum(sum, sh.sum, nsum);  // P_{first-1}
+    float bk[EB], ck[EB];
+    load_block<EB>(b, first - 1 - OFF, 0, N - 1, 0.0f, bk);  // k index of element j is j - 1 - OFF
+    load_block<EB>(c, first - 1 - OFF, 0, N - 1, 0.0f, ck);
+    Aff st[EB];
+    Aff A = aff_identity();
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+      const long j = first + e;
+      st[e] = aff_identity();
+      if (j >= 1 && j < N) st[e] = step_map(bk[e] * ck[e], wv[e], tau[e], inv[e], Prun);  // c0 = P_{j-1}
+      else wv[e] = make_float2(0.f, 0.f);
+      Prun = cadd(Prun, make_float2(q[2 * e], q[2 * e + 1]));
+      A = compose(st[e], A);
+    }
+    float2 x = block_exclusive_aff(A, sh.aff, naff);  // mu_{first-1} / s_{first-1}
+    float av[EB], gav[EB], gkv[EB];
+    load_block<EB>(a, first, 0, N, 0.0f, av);
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+      const long j = first + e;
+      gkv[e] = -fmaf(x.x, wv[e].x, -x.y * wv[e].y);
+      gav[e] = 0.0f;
+      if (j < N) {
+        x = apply(st[e], x);
+        if (j >= 1) gav[e] = times_dreg(x, av[e], z);
+      }
+    }
+    store_block<EB>(ga, first, 0, N, gav);
+    // element j >= 1 wrote the phi part of grad_k at index j - 1 - OFF (0 from j = 1: mu_0 = 0)
+    if (gk) store_block<EB>(gk, first - 1 - OFF, 0, N - 1 - OFF, gkv);
+  }
+  const int any_bad = __syncthreads_or(bad ? 1 : 0);
+  if (t == 0) {
+    qtot[row] = sh.sum.carry[nsum & 1];   // sum of q over the row
+    rowbad[row] = any_bad;
+    if (any_bad) __hip_atomic_store(&state[5], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <int OFF>
+__global__ __launch_bounds__(T) void bk_adjoint_sweep_theta(
+    const float *__restrict__ a_, long lda, const float *__restrict__ b_, long ldb, const float *__restrict__ c_,
+    long ldc, const float *__restrict__ z_dev, float z_re, float z_im, long N, const float *__restrict__ G_,
+    const float *__restrict__ gf_, const float *__restrict__ gG_, float *__restrict__ ga_, float *__restrict__ gb_,
+    float *__restrict__ gc_, const float2 *__restrict__ qtot, int *__restrict__ rowbad, int *state) {
+  __shared__ SharedSweep sh;
+  const long row = blockIdx.x;
+  const float *a = a_ + row * lda;
+  const float *b = N >= 2 ? b_ + row * ldb : a, *c = N >= 2 ? c_ + row * ldc : a;
+  const float *G = G_ + row * N * 2;
+  const float *gf = gf_ ? gf_ + row * N * 2 : nullptr, *gG = gG_ ? gG_ + row * N * 2 : nullptr;
+  float *ga = ga_ + row * N;
+  float *gb = gb_ ? gb_ + row * (N - 1) : nullptr;
+  float *gc = gc_ ? gc_ + row * (N - 1) : nullptr;
+  const float2 z = z_dev ? make_float2(z_dev[0], z_dev[1]) : make_float2(z_re, z_im);
+  const float2 Q = qtot[row];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int nch = (int)((N + CHUNK - 1) / CHUNK);
+  int nsum = 0, naff = 0;
+  bool bad = false;
+  if (t == 0) {
+    sh.aff.carry[0] = make_float2(0.f, 0.f);
+    sh.sum.carry[0] = make_float2(0.f, 0.f);
+  }
+  for (int ch = nch - 1; ch >= 0; --ch) {
+    const long base = (long)ch * CHUNK;
+    const int seg = T - 1 - t;  // descending segments over ascending threads
+    const long first = base + (long)seg * EB;
+    __syncthreads();
+    stage_rows(a, b, c, base, N, z, sh.st);
+    __syncthreads();
+    const float2 *al_l = sh.st.al_s + spad(WH + seg * EB);
+    const float *k_l = sh.st.k_s + spad(WH + seg * EB);
+    // theta: warm-up over the 16 elements to the left (slots of negative offset), then the lane's own, left -> right
+    float2 om = make_float2(0.f, 0.f), inv[EB], wv[EB];
+    float tau[EB], lmin = 0.0f, ldummy = 0.0f;
+#pragma unroll
+    for (int j = 0; j < WH; ++j) {
+      const int d = j - WH;                                  // -16 .. -1
+      const int off = d - (EB - 1 - d) / EB;                  // padded offset of slot d < 0 from the lane's first slot
+      float2 iv;
+      float tv;
+      if (j < WH / 2) om = om_coarse(al_l[off], k_l[off], om);
+      else om = om_full(al_l[off], k_l[off], om, iv, tv, ldummy);
+    }
+    const float2 west = om;
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+      om = om_full(al_l[e], k_l[e], om, inv[e], tau[e], lmin);
+      wv[e] = om;
+    }
+    {
+      // the right neighbour (thread t - 1) ran its warm-up over this lane's elements
+      const int buf = ch & 1;
+      if (lane == 63) sh.wedge[buf][wave] = west;
+      if (t == T - 1) sh.edge[buf] = west;
+      float2 nb = make_float2(dpp_f<0x138, 0xF>(0.f, west.x), dpp_f<0x138, 0xF>(0.f, west.y));
+      __syncthreads();
+      if (lane == 0) nb = wave > 0 ? sh.wedge[buf][wave - 1] : sh.edge[buf ^ 1];
+      if ((t > 0 || ch < nch - 1) && first + EB < N) bad |= om_differs(nb, om);
+      if (first < N) bad |= !(lmin >= -13.3f);
+    }
+    float q[2 * EB];
+    lane_q(G, gf, gG, first, N, q);
+    float2 sum = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int e = 0; e < EB; ++e) sum = cadd(sum, make_float2(q[2 * e], q[2 * e + 1]));
+    float2 Srun = block_exclusive_sum(sum, sh.sum, nsum);  // sum of q over the elements to the right of the lane's
+    float bk[EB], ck[EB];
+    load_block<EB>(b, first, 0, N - 1, 0.0f, bk);
+    load_block<EB>(c, first, 0, N - 1, 0.0f, ck);
+    Aff st[EB];
+    Aff A = aff_identity();
+#pragma unroll
+    for (int qi = 0; qi < EB; ++qi) {
+      const int e = EB - 1 - qi;
+      const long j = first + e;
+      st[e] = aff_identity();
+      if (j < N) {
+        // P_j = Q - sum_{j' > j} q_j'
+        st[e] = step_map(bk[e] * ck[e], wv[e], tau[e], inv[e], make_float2(Srun.x - Q.x, Srun.y - Q.y));
+      } else {
+        wv[e] = make_float2(0.f, 0.f);
+      }
+      Srun = cadd(Srun, make_float2(q[2 * e], q[2 * e + 1]));
+      A = compose(st[e], A);
+    }
+    float2 x = block_exclusive_aff(A, sh.aff, naff);  // lam_{j+1} / r_{j+1} for the lane's last element j
+    float av[EB], gav[EB], gkp[EB], gbv[EB], gcv[EB];
+    load_block<EB>(a, first, 0, N, 0.0f, av);
+    load_block<EB>(ga, first, 0, N, 0.0f, gav);
+    if (gb) {
+      load_block<EB>(gb, first, 0, N - 1 - OFF, 0.0f, gkp);  // the phi part of grad_k, left there by the phi sweep
+    } else {
+#pragma unroll
+      for (int e = 0; e < EB; ++e) gkp[e] = 0.0f;
+    }
+#pragma unroll
+    for (int qi = 0; qi < EB; ++qi) {
+      const int e = EB - 1 - qi;
+      const long j = first + e;
+      const float gk = gkp[e] - fmaf(x.x, wv[e].x, -x.y * wv[e].y);
+      if (j < N) x = apply(st[e], x);
+      gav[e] = finite_or_zero(gav[e] + times_dreg(x, av[e], z));
+      gbv[e] = finite_or_zero(ck[e] * gk);
+      gcv[e] = finite_or_zero(bk[e] * gk);
+    }
+    store_block<EB>(ga, first, 0, N, gav);
+    if (gb) {
+      store_block<EB>(gb, first, 0, N - 1, gbv);
+      store_block<EB>(gc, first, 0, N - 1, gcv);
+    }
+  }
+  const int any_bad = __syncthreads_or(bad ? 1 : 0);
+  if (t == 0 && any_bad) {
+    rowbad[row] = 1;
+    __hip_atomic_store(&state[5], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ void bk_adjoint_finish(int *state) {
+  if (threadIdx.x == 0) __hip_atomic_store(&state[5], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t bkcore_backward_analytic_workspace_bytes(int64_t B, int64_t N) {
   if (B <= 0 || N <= 0) return 0;
-  // forward scratch + G_raw + r + s + P  (complex64 each)
-  return ((bkcore_workspace_bytes(B, N) + 255) & ~(size_t)255) + 4 * (size_t)B * (size_t)N * 2 * sizeof(float);
+  // forward scratch + four complex64 planes (G_raw, r, s, P of the three-pass path; the P plane also takes G when the
+  // caller did not keep it) + one flag and one complex sum per row
+  return ((bkcore_workspace_bytes(B, N) + 255) & ~(size_t)255) + 4 * (size_t)B * (size_t)N * 2 * sizeof(float) +
+         (((size_t)B * sizeof(int) + 255) & ~(size_t)255) + (size_t)B * 2 * sizeof(float);
 }
 
 int bkcore_backward_analytic(const float *a, int64_t lda, const float *b, int64_t ldb, const float *c, int64_t ldc,
-                             const float *z_dev, float z_re, float z_im, int64_t B, int64_t N,
+                             const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, const float *G_saved,
                              const float *grad_features, const float *grad_G, float *grad_a, float *grad_b,
                              float *grad_c, void *workspace, size_t workspace_bytes, void *state, unsigned flags,
                              void *stream) {
@@ -452,6 +817,7 @@ int bkcore_backward_analytic(const float *a, int64_t lda, const float *b, int64_
   if ((grad_b == nullptr) != (grad_c == nullptr)) return BKCORE_EINVAL;
   if (flags & ~BKCORE_FLAG_PHI_EXACT) return BKCORE_EINVAL;
   if (N > bkcore_max_seq_len()) return BKCORE_ETOOLONG;
+  if (B > 2147483647LL) return BKCORE_EINVAL;
   const size_t need = bkcore_backward_analytic_workspace_bytes(B, N);
   if (!workspace || workspace_bytes < need) return BKCORE_EWORKSPACE;
   char *ws = (char *)workspace;
@@ -461,27 +827,58 @@ int bkcore_backward_analytic(const float *a, int64_t lda, const float *b, int64_
   float *sr = (float *)(ws + fwd_ws + plane);
   float *ss = (float *)(ws + fwd_ws + 2 * plane);
   float *Pp = (float *)(ws + fwd_ws + 3 * plane);
-  // 1. the forward again, keeping the theta / phi ratios and G before its final clamps (inputs are already
-  //    sanitised, hence RAW)
-  const unsigned fflags = BKCORE_FLAG_RAW | (flags & BKCORE_FLAG_PHI_EXACT);
-  const int rc = bkcore_internal_forward_save(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, Graw, ws, state, fflags,
-                                              stream, sr, ss);
-  if (rc != BKCORE_OK) return rc;
+  int *rowbad = (int *)(ws + fwd_ws + 4 * plane);
+  float2 *qtot = (float2 *)(ws + fwd_ws + 4 * plane + (((size_t)B * sizeof(int) + 255) & ~(size_t)255));
   hipStream_t s = (hipStream_t)stream;
   float *gk = N > 1 ? grad_b : nullptr;
   float *gc = N > 1 ? grad_c : nullptr;
+  const unsigned fflags = BKCORE_FLAG_RAW | (flags & BKCORE_FLAG_PHI_EXACT);  // inputs are already sanitised
+  const int *filter = nullptr, *gate = nullptr;
+  if (state) {
+    // 1. the two sweeps, on the forward's own output
+    const float *G = G_saved;
+    if (!G) {
+      const int rc = bkcore_forward(a, lda, b, ldb, c, ldc, BKCORE_F32, z_dev, z_re, z_im, B, N, Pp, nullptr, ws, fwd_ws,
+                                    state, fflags, stream);
+      if (rc != BKCORE_OK) return rc;
+      G = Pp;
+    }
+    int *st = (int *)state;
+#define BK_LAUNCH_SWEEPS(OFF)                                                                                         \
+  hipLaunchKernelGGL((bk_adjoint_sweep_phi<OFF>), dim3((unsigned)B), dim3(T), 0, s, a, (long)lda, b, (long)ldb, c,   \
+                     (long)ldc, z_dev, z_re, z_im, (long)N, G, grad_features, grad_G, grad_a, gk, qtot, rowbad, st);  \
+  hipLaunchKernelGGL((bk_adjoint_sweep_theta<OFF>), dim3((unsigned)B), dim3(T), 0, s, a, (long)lda, b, (long)ldb, c, \
+                     (long)ldc, z_dev, z_re, z_im, (long)N, G, grad_features, grad_G, grad_a, gk, gc,                 \
+                     (const float2 *)qtot, rowbad, st)
+    if (flags & BKCORE_FLAG_PHI_EXACT) {
+      BK_LAUNCH_SWEEPS(0);
+    } else {
+      BK_LAUNCH_SWEEPS(1);
+    }
+#undef BK_LAUNCH_SWEEPS
+    filter = rowbad;
+    gate = st + 5;
+  }
+  // 2. the three-pass path (forward keeping the theta / phi ratios and G before its final clamps, then the two adjoint
+  //    kernels on them): every row when there is no state block, otherwise only rows whose checks failed in a sweep --
+  //    each launch returns at once unless state[5] is up
+  const int rc = bkcore_internal_forward_save_rows(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, Graw, ws, fflags,
+                                                   stream, sr, ss, filter, gate);
+  if (rc != BKCORE_OK) return rc;
 #define BK_LAUNCH_ADJ(OFF)                                                                                            \
   hipLaunchKernelGGL((bk_adjoint_phi_kernel<OFF>), dim3((unsigned)B), dim3(T), 0, s, a, (long)lda, b, (long)ldb, c,  \
                      (long)ldc, z_dev, z_re, z_im, (long)N, (const float *)Graw, grad_features, grad_G,               \
-                     (const float *)ss, Pp, grad_a, gk);                                                              \
+                     (const float *)ss, Pp, grad_a, gk, filter, gate);                                                \
   hipLaunchKernelGGL((bk_adjoint_theta_kernel<OFF>), dim3((unsigned)B), dim3(T), 0, s, a, (long)lda, b, (long)ldb,   \
-                     c, (long)ldc, z_dev, z_re, z_im, (long)N, (const float *)sr, (const float *)Pp, grad_a, gk, gc)
+                     c, (long)ldc, z_dev, z_re, z_im, (long)N, (const float *)sr, (const float *)Pp, grad_a, gk, gc,  \
+                     filter, gate)
   if (flags & BKCORE_FLAG_PHI_EXACT) {
     BK_LAUNCH_ADJ(0);
   } else {
     BK_LAUNCH_ADJ(1);
   }
 #undef BK_LAUNCH_ADJ
+  if (state) hipLaunchKernelGGL(bk_adjoint_finish, dim3(1), dim3(64), 0, s, (int *)state);
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) {
     bkcore_internal_set_hip_error((int)err);

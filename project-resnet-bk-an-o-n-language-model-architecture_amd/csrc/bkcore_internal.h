@@ -12,6 +12,13 @@ extern "C" __attribute__((visibility("hidden"))) int bkcore_internal_forward_sav
     float z_re, float z_im, int64_t B, int64_t N, float *G, void *workspace, void *state, unsigned flags, void *stream,
     float *save_r, float *save_s);
 
+// The same by one launch of the two-scan kernel, for the rows with row_filter[row] != 0 (every row when NULL) and only
+// if *gate != 0 (always when NULL): the analytic backward's path for rows its sweeps flagged.
+extern "C" __attribute__((visibility("hidden"))) int bkcore_internal_forward_save_rows(
+    const float *a, int64_t lda, const float *b, int64_t ldb, const float *c, int64_t ldc, const float *z_dev,
+    float z_re, float z_im, int64_t B, int64_t N, float *G, void *workspace, unsigned flags, void *stream,
+    float *save_r, float *save_s, const int *row_filter, const int *gate);
+
 // Launches of the ratio-form forward (bkcore_ratio.hip); errors are left for the caller's hipGetLastError().
 // mode 0: one workgroup per row (save != 0: the variant that also stores r, s and writes G_raw); mode 1 / 2: per-segment
 // products / per-segment outputs of rows cut into S segments of seg_ch chunks, around bkcore_internal_ratio_combine.

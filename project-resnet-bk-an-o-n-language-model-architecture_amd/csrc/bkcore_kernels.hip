@@ -575,9 +575,14 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
     const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
     const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, float2 *__restrict__ G_,
     float2 *__restrict__ F_, char *__restrict__ ws, int *state, int second, unsigned flags, float fclamp,
-    float2 *__restrict__ save_r_, float2 *__restrict__ save_s_) {
+    float2 *__restrict__ save_r_, float2 *__restrict__ save_s_, const int *__restrict__ row_filter = nullptr,
+    const int *gate = nullptr) {
   __shared__ Shared sh;
   const long row = blockIdx.x;
+  // the analytic backward's launches for the rows its sweeps flagged: nothing to do unless *gate is up, and then only
+  // for rows with row_filter[row] != 0
+  if (gate && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+  if (row_filter && row_filter[row] == 0) return;
   int *rowflag = reinterpret_cast<int *>(ws);
   bool fix_bc = false;
   if (second) {
@@ -1443,6 +1448,28 @@ int bkcore_internal_forward_save(const float *a, int64_t lda, const float *b, in
                                              state, flags, s, save_r, save_s);
 }
 
+int bkcore_internal_forward_save_rows(const float *a, int64_t lda, const float *b, int64_t ldb, const float *c,
+                                      int64_t ldc, const float *z_dev, float z_re, float z_im, int64_t B, int64_t N,
+                                      float *G, void *workspace, unsigned flags, void *stream, float *save_r,
+                                      float *save_s, const int *row_filter, const int *gate) {
+  // one launch of the two-scan kernel (it needs no verification and no state block), saving variant
+  hipStream_t s = (hipStream_t)stream;
+#define BK_SAVE_ROWS(EXACT)                                                                                          \
+  hipLaunchKernelGGL((bk_forward_kernel<float, EXACT, false, true>), dim3((unsigned)B), dim3(T), 0, s, a, (long)lda, \
+                     b, (long)ldb, c, (long)ldc, z_dev, z_re, z_im, (long)B, (long)N, (float2 *)G, (float2 *)nullptr, \
+                     (char *)workspace, (int *)nullptr, 0, flags, __builtin_huge_valf(), (float2 *)save_r,           \
+                     (float2 *)save_s, row_filter, gate)
+  if (flags & BKCORE_FLAG_PHI_EXACT) BK_SAVE_ROWS(true);
+  else BK_SAVE_ROWS(false);
+#undef BK_SAVE_ROWS
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    g_last_hip_error = (int)err;
+    return BKCORE_ELAUNCH;
+  }
+  return BKCORE_OK;
+}
+
 int bkcore_backward_ref(const float *G, const float *grad_features, const float *grad_G, float alpha, int64_t n,
                         float *grad_a, void *stream) {
   if (n < 0) return BKCORE_EINVAL;
@@ -1535,7 +1562,7 @@ int bkcore_layer_backward_ref(const float *G, const float *grad_features, const 
 int64_t bkcore_max_seq_len(void) { return (int64_t)MAX_N; }
 int bkcore_last_hip_error(void) { return g_last_hip_error; }
 void bkcore_internal_set_hip_error(int code) { g_last_hip_error = code; }
-int bkcore_abi_version(void) { return 9; }
+int bkcore_abi_version(void) { return 10; }
 
 const char *bkcore_error_string(int code) {
   switch (code) {

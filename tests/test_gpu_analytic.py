@@ -171,10 +171,10 @@ def test_argument_checks(bk):
     ga = torch.empty(2, 64, device="cuda")
     ws = torch.empty(256, dtype=torch.uint8, device="cuda")
     rc = L.bkcore_backward_analytic(a.data_ptr(), 64, b.data_ptr(), 63, b.data_ptr(), 63, None, 0.0, 1.0, 2, 64,
-                                    None, None, ga.data_ptr(), None, None, ws.data_ptr(), 256, None, 0, None)
+                                    None, None, None, ga.data_ptr(), None, None, ws.data_ptr(), 256, None, 0, None)
     assert rc == _lib.EWORKSPACE
     rc = L.bkcore_backward_analytic(a.data_ptr(), 64, b.data_ptr(), 63, b.data_ptr(), 63, None, 0.0, 1.0, 2, 64,
-                                    None, None, ga.data_ptr(), ga.data_ptr(), None, ws.data_ptr(), 256, None, 0, None)
+                                    None, None, None, ga.data_ptr(), ga.data_ptr(), None, ws.data_ptr(), 256, None, 0, None)
     assert rc == _lib.EINVAL
     with pytest.raises(RuntimeError):
         bk.bk_backward_analytic(a.cpu(), b.cpu(), b.cpu(), 1j, None, None)

@@ -21,13 +21,15 @@ g = torch.Generator(device="cuda").manual_seed(0)
 a = -2.0 + 0.5 * torch.randn(B, N, device="cuda", generator=g)
 b = torch.ones(B, N - 1, device="cuda"); c = torch.ones(B, N - 1, device="cuda")
 gf = torch.randn(B, N, 2, device="cuda", generator=g)
-for want_bc in (True, False):
+_, G = bkcore.bk_forward(a, b, c, 1j)
+for want_bc, Gs in ((True, G), (True, None), (False, G)):
     for _ in range(3):
-        bkcore.bk_backward_analytic(a, b, c, 1j, gf, None, want_bc=want_bc)
+        bkcore.bk_backward_analytic(a, b, c, 1j, gf, None, want_bc=want_bc, G=Gs)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
-        bkcore.bk_backward_analytic(a, b, c, 1j, gf, None, want_bc=want_bc)
+        bkcore.bk_backward_analytic(a, b, c, 1j, gf, None, want_bc=want_bc, G=Gs)
     e1.record(); torch.cuda.synchronize()
-    print(f"analytic backward B={B} N={N} want_bc={want_bc}: {e0.elapsed_time(e1)/10:.3f} ms", flush=True)
+    print(f"analytic backward B={B} N={N} want_bc={want_bc} G={'saved' if Gs is not None else 'recomputed'}: "
+          f"{e0.elapsed_time(e1)/10:.3f} ms", flush=True)
