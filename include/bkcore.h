@@ -124,6 +124,9 @@ int bkcore_backward_analytic(const float *a, int64_t lda, const float *b, int64_
                              float *grad_c, void *workspace, size_t workspace_bytes, void *state, unsigned flags,
                              void *stream);
 size_t bkcore_backward_analytic_workspace_bytes(int64_t B, int64_t N);
+/* Diagnostics: byte offset, inside the workspace of bkcore_backward_analytic(B, N), of B ints that are non-zero after
+ * the call for the rows the three-pass path recomputed (valid when state was given).  No counterpart in the reference. */
+size_t bkcore_backward_analytic_rowflag_offset(int64_t B, int64_t N);
 
 /*
  * bkcore_forward with the caller's clamp of the features folded into the store: features = clamp((Re G, Im G),

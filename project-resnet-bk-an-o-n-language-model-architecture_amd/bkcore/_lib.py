@@ -19,7 +19,7 @@ EINVAL, ETOOLONG, ELAUNCH, EWORKSPACE, ETOOBIG = -1, -2, -3, -4, -5
 NOALLOC_MAX_WORKSPACE = 8 << 20
 
 EXPORTS = ("bkcore_forward", "bkcore_forward_clamped", "bkcore_forward_noalloc", "bkcore_workspace_bytes", "bkcore_backward_ref", "bkcore_backward_analytic",
-           "bkcore_backward_analytic_workspace_bytes", "bkcore_layer_prologue", "bkcore_layer_backward_ref",
+           "bkcore_backward_analytic_workspace_bytes", "bkcore_backward_analytic_rowflag_offset", "bkcore_layer_prologue", "bkcore_layer_backward_ref",
            "bkcore_layer_epilogue", "bkcore_layer_epilogue_backward", "bkcore_layer_epilogue_backward_workspace_bytes", "bkcore_cumsum", "bkcore_woodbury_correct", "bkcore_woodbury_workspace_bytes",
            "bkcore_max_seq_len", "bkcore_last_hip_error",
            "bkcore_error_string", "bkcore_abi_version")
@@ -55,6 +55,8 @@ def load():
     L.bkcore_backward_analytic.restype = i32
     L.bkcore_backward_analytic_workspace_bytes.argtypes = [i64, i64]
     L.bkcore_backward_analytic_workspace_bytes.restype = ctypes.c_size_t
+    L.bkcore_backward_analytic_rowflag_offset.argtypes = [i64, i64]
+    L.bkcore_backward_analytic_rowflag_offset.restype = ctypes.c_size_t
     L.bkcore_layer_prologue.argtypes = [vp, i64, vp, f32, i64, i64, vp, i32, vp]
     L.bkcore_layer_prologue.restype = i32
     L.bkcore_layer_backward_ref.argtypes = [vp, vp, vp, f32, f32, vp, f32, i32, i64, vp, vp]

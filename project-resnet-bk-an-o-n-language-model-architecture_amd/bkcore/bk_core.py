@@ -342,8 +342,21 @@ def bk_backward_analytic(a, b, c, z, grad_features, grad_G, phi_exact: bool = Fa
                                         gc.data_ptr() if gc is not None and nb else None, ws.data_ptr(), ws_bytes,
                                         state.data_ptr(), _lib.FLAG_PHI_EXACT if phi_exact else 0, stream)
     _lib.check(rc, "bkcore_backward_analytic")
+    if _DEBUG["keep_ws"]:
+        _DEBUG["last_ana_ws"], _DEBUG["last_ana_shape"] = ws, (B, N)
     del zkeep
     return ga, gb, gc
+
+
+def analytic_rows_recomputed() -> int:
+    """Diagnostics: number of rows of the last analytic backward (run with _DEBUG['keep_ws'] = True) whose in-kernel
+    checks failed, so that the three-pass path recomputed them."""
+    ws = _DEBUG.get("last_ana_ws")
+    if ws is None:
+        raise RuntimeError("bkcore: no analytic backward was run with _DEBUG['keep_ws'] = True")
+    B, N = _DEBUG["last_ana_shape"]
+    off = int(_lib.load().bkcore_backward_analytic_rowflag_offset(B, N))
+    return int(ws[off: off + 4 * B].view(torch.int32).ne(0).sum().item())
 
 
 def vmapped_get_diag(a, b, c, z):
