@@ -32,6 +32,7 @@ for p in (ROOT, PKG):
 FWD_BYTES = 20.0   # per diag-element: a,b,c reads (3x4) + G write (8); the features are the float32 view of G
 FWD_BYTES_TWO = 28.0  # the same with the features written as a second tensor (SHARE_FEATURES_STORAGE = False)
 BWD_BYTES = 20.0   # per diag-element: G read (8) + grad_features read (8) + grad_he_diag write (4)
+ANA_BYTES = 40.0   # analytic backward, per diag-element: a,b,c (12) + G (8) + grad_features (8) read, grad_a,b,c (12) written
 HBM_PEAK = 8.0e12  # MI355X HBM3E nominal bytes/s
 
 
@@ -319,7 +320,32 @@ def secondary_measurements(torch, bkcore, device, B, N, ad, b, c, z, gfeat, time
                                    "fwd_ms_median": f_med, "fwd_ms_min": f_min}
         # analytic-mode backward at the same size, and the long-context configuration BASELINE.json configs[2]
         # (B=16, N=2^20: several workgroups per row)
-        t_ana = timed(lambda: bkcore.bk_backward_analytic(ad, b, c, z, gfeat, None), 5)
+        Gs = bkcore.bk_forward(ad, b, c, z, share_storage=share)[1]
+        t_ana = timed(lambda: bkcore.bk_backward_analytic(ad, b, c, z, gfeat, None, G=Gs), 10)
+        t_ana_a = timed(lambda: bkcore.bk_backward_analytic(ad, b, c, z, gfeat, None, want_bc=False, G=Gs), 10)
+        t_fwd_now = timed(lambda: bkcore.bk_forward(ad, b, c, z, share_storage=share), 10)
+        t_fwd_two = timed(lambda: bkcore.bk_forward(ad, b, c, z, share_storage=False), 10)
+        del Gs
+        elems = float(B) * float(N)
+        tr = None
+        try:
+            here = os.path.dirname(os.path.abspath(__file__))
+            with open(os.path.join(here, "profiles", "traffic_analytic_latest.json")) as fh:
+                tr = float(json.load(fh)["analytic_traffic_bytes_per_launch_corrected"])
+        except Exception:
+            tr = None
+        out["roofline_analytic"] = {
+            "kernel": "bk_adjoint_sweeps (GRAD_MODE = 'analytic': gradients for he_diag, h0_super, h0_sub)",
+            "bound": "hbm", "bytes_per_elem": ANA_BYTES, "launch_ms": t_ana * 1e3,
+            "achieved": ANA_BYTES * elems / t_ana / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": ANA_BYTES * elems / t_ana / HBM_PEAK, "traffic": tr,
+            "he_diag_only_ms": t_ana_a * 1e3,
+            "fwd_plus_analytic_bwd": {
+                "bytes_per_elem": FWD_BYTES + ANA_BYTES, "ms": (t_fwd_now + t_ana) * 1e3,
+                "frac": (FWD_BYTES + ANA_BYTES) * elems / (t_fwd_now + t_ana) / HBM_PEAK},
+            "fwd_two_outputs_plus_analytic_bwd": {
+                "bytes_per_elem": FWD_BYTES_TWO + ANA_BYTES, "ms": (t_fwd_two + t_ana) * 1e3,
+                "frac": (FWD_BYTES_TWO + ANA_BYTES) * elems / (t_fwd_two + t_ana) / HBM_PEAK}}
         a3, b3, c3, z3, g3 = make_inputs(16, 1 << 20, device, 99)
         a3 = a3.detach()
         G3 = bkcore.bk_forward(a3, b3, c3, z3)[1]

@@ -438,24 +438,23 @@ __global__ __launch_bounds__(T) void bk_adjoint_theta_kernel(
 }
 
 
-// ==== both sweeps in one kernel, the ratios recomputed in it =======================================================
+// ==== one pass over the row, the ratios recomputed in it ===========================================================
 // Nothing but G is kept from the forward (as in the reference, bk_core.py:293).  The cotangent of G_raw follows from G
 // itself: with X = conj(gbar) G,  q = X - tanh^2(L_raw/88) Re X  and  tanh(L_raw/88) = ln|G| / 88  (the final clamp is
 // ln|G| = 88 tanh(L_raw/88)); a clipped element (|G| = 50) passes only Im X; G = 0 passes nothing.  The ratios r and s
 // are recomputed from a, b, c exactly as the forward does: wherever the ratio maps contract, a lane gets the ratio
 // entering its 8 elements by running the map over the 16 elements before them (after them, for s), verified against
 // the neighbouring lane's own value.  The adjoint recurrences contract at the same rate (their linear part is
-// k w(r) / r), so the value entering a lane is taken from the two lanes before it,
+// k w(r) / r), so the value entering a lane is taken from the two lanes before it (after it, for lam),
 //     x_in(l) = v(l-1) + m(l-1) v(l-2),     v = the lane's 8 maps applied to 0,  m = the product of their linear parts,
-// checked by |m(l-1) m(l-2)| <= 2e-5.  One workgroup per row runs
-//   phase phi   : chunks left -> right : s, P (prefix sums of q), mu; writes the phi part of grad_a and of grad_k
-//                 into the output buffers
-//   phase theta : chunks right -> left : r, P = total - suffix sums, lam; adds the theta parts, writes grad_a, grad_b,
-//                 grad_c  (it starts where the first phase ended, on data that is still in the caches)
-// with a, b, c, G and the cotangent staged through LDS by coalesced loads.  A row with a failed check is flagged
-// (rowbad[row], state[5]) and recomputed by the three-pass path above, whose launches follow and skip every other row.
-// development: BK_SWEEP_STAMPS=1 writes s_memtime stamps of thread 0 at the stage boundaries of every chunk of both
-// phases into dbg (8 slots of 8 bytes per (row, phase, chunk))
+// checked by |m(l-1) m(l-2)| <= 2e-5.  One workgroup per row walks left -> right over chunks of 256 lanes x 8 elements
+// that overlap by two lanes: mu enters a chunk exactly (carried from the chunk before), lam enters its last lane as 0,
+// which is exact at the end of the row and otherwise only reaches the two overlap lanes, whose results the next chunk
+// produces instead.  So a, b, c, G and the cotangent are read once (coalesced, through LDS) and grad_a, grad_b,
+// grad_c written once.  A row with a failed check is flagged (rowbad[row], state[5]) and recomputed by the three-pass
+// path above, whose launches follow and skip every other row.
+// development: BK_SWEEP_STAMPS=1 writes s_memtime stamps of thread 0 at the stage boundaries of every chunk into dbg
+// (8 slots of 8 bytes per (row, chunk))
 #ifndef BK_SWEEP_STAMPS
 #define BK_SWEEP_STAMPS 0
 #endif
@@ -464,14 +463,14 @@ __global__ __launch_bounds__(T) void bk_adjoint_theta_kernel(
   do {                                                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     const unsigned long long tm_ = __builtin_amdgcn_s_memtime();                                                     \
-    if (threadIdx.x == 0) dbg[(((long)blockIdx.x * 2 + (THETA ? 1 : 0)) * nch + cc) * 8 + (k)] = tm_;                \
+    if (threadIdx.x == 0) dbg[((long)blockIdx.x * nch + cc) * 8 + (k)] = tm_;                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
   } while (0)
 #else
 #define BK_SSTAMP(k) do { } while (0)
 #endif
 #ifndef BK_SWEEP_PREFETCH
-#define BK_SWEEP_PREFETCH 1   // raw inputs of the next chunk held in registers during the current chunk's arithmetic
+#define BK_SWEEP_PREFETCH 0   // 1: raw inputs of the next chunk held in registers during the current chunk's arithmetic
 #endif
 #ifndef BK_SWEEP_WG
 #define BK_SWEEP_WG 2   // workgroups per CU the register budget is set for
@@ -484,17 +483,22 @@ static_assert(SN % EB == 0 && WH % EB == 0, "padded slot arithmetic");
 // offset of slot d (may be negative) from a slot whose index is a multiple of EB, in the layout q -> q + q / EB
 __device__ __forceinline__ constexpr int soff(int d) { return d + (d >= 0 ? d / EB : -((EB - 1 - d) / EB)); }
 
+constexpr int HALO_LANES = 2;                       // lanes at the end of a chunk that the next chunk computes again
+constexpr int STRIDE = CHUNK - HALO_LANES * EB;     // elements a chunk advances by
 struct SharedSweep {
   float2 al_s[SPAD];            // regularised diagonal of elements base - WH .. base + CHUNK + WH - 1
-  float k_s[SPAD];              // theta: k_{i-1};  phi: kphi_i (0 from the last element on)
+  float k_s[SPAD];              // k_{i-1} = b_{i-1} c_{i-1} for the same elements (0 outside the row)
   float2 q_s[QPAD];             // q of elements base .. base + CHUNK - 1
   float a_s[QPAD];              // he_diag of the same elements
-  float2 bc_s[QPAD];            // theta: (b_j, c_j) of the same elements
+  float2 bc_s[QPAD];            // (b_j, c_j) of the same elements
   float2 sumtot[2][WAVES];
   float2 sumcarry[2];
-  float2 wedge[2][WAVES];       // last lane of each wave: its warm-up estimate, for the first lane of the next wave
-  float2 edge[2];               // the same from the last lane of the chunk processed before
-  float4 xedge[2][WAVES][2];    // (v, m) of lanes 62 and 63 of each wave
+  float2 wedge_t[2][WAVES];     // theta: lane 63 of each wave, om after its last own step
+  float2 wedge_p[2][WAVES];     // phi: lane 63 of each wave, its warm-up estimate
+  float2 edge_t[2], edge_p[2];  // the same of lane T - 3, the left neighbour of the next chunk's first lane
+  float4 xe_p[2][WAVES][2];     // mu: (v, m) of lanes 62 and 63 of each wave
+  float4 xe_t[2][WAVES][2];     // lam: (v, m) of lanes 0 and 1 of each wave
+  float4 xc_p[2][2];            // mu: (v, m) of lanes T - 4 and T - 3
 };
 
 constexpr float WALL_C = 0.69314718055994531f / 176.0f;
@@ -571,59 +575,63 @@ struct Raw {
   float2 Gv[EB], gv[EB];
 };
 
-// CHECK = false when every staged element and its off-diagonal entries lie inside the row.
-template <int OFF, bool THETA, bool CHECK>
+// CHECK = false when every staged element and its off-diagonal entries lie inside the row.  Addresses are a uniform
+// pointer plus a small per-thread offset, so that no 64-bit address per load has to be kept in vector registers.
+template <bool CHECK>
 __device__ __forceinline__ void issue_loads(const float *__restrict__ a, const float *__restrict__ b,
                                             const float *__restrict__ c, const float *__restrict__ G,
-                                            const float *__restrict__ gf, long base, long N, Raw &R) {
-  const int t = threadIdx.x;
-  constexpr int KSH = THETA ? 1 : OFF;  // slot i holds k_{i - KSH}
+                                            const float *__restrict__ gf, long base, long N, Raw &R, int t) {
+  const float *__restrict__ pa = a + (base - WH);       // slot q: a[base - WH + q]
+  const float *__restrict__ pb = b + (base - WH - 1);   // slot q holds k_{i-1}, i = base - WH + q
+  const float *__restrict__ pc = c + (base - WH - 1);
+  const float *__restrict__ pG = G + 2 * base;
+  const float *__restrict__ pg = gf ? gf + 2 * base : nullptr;
+  // slots with an element inside the row: q in [qa0, qa1); with an off-diagonal entry: q in [qk0, qk1)
+  const long qa0 = WH - base, qa1 = N - base + WH, qk0 = WH + 1 - base, qk1 = N - base + WH;
+  const int ia0 = (int)(qa0 < 0 ? 0 : (qa0 > SN ? SN : qa0)), ia1 = (int)(qa1 > SN ? SN : (qa1 < 0 ? 0 : qa1));
+  const int ik0 = (int)(qk0 < 0 ? 0 : (qk0 > SN ? SN : qk0)), ik1 = (int)(qk1 > SN ? SN : (qk1 < 0 ? 0 : qk1));
+  const long ng = N - base;
+  const int ig1 = (int)(ng > CHUNK ? CHUNK : (ng < 0 ? 0 : ng));
 #pragma unroll
   for (int j = 0; j < ROUNDS; ++j) {
     const int q = t + j * T;
-    const long i = base - WH + q, ki = i - KSH;
     R.av[j] = 1.0f;
     R.bv[j] = 0.0f;
     R.cv[j] = 0.0f;
     if (CHECK) {
-      const bool in = (j < ROUNDS - 1 || q < SN);
-      if (in && i >= 0 && i < N) R.av[j] = __builtin_nontemporal_load(a + i);
-      // phi: kphi is 0 from the last element on (the recurrence starts there)
-      if (in && ki >= 0 && ki <= N - 2 && (THETA || i <= N - 2)) {
-        R.bv[j] = __builtin_nontemporal_load(b + ki);
-        R.cv[j] = __builtin_nontemporal_load(c + ki);
+      if (q >= ia0 && q < ia1) R.av[j] = __builtin_nontemporal_load(pa + q);
+      if (q >= ik0 && q < ik1) {
+        R.bv[j] = __builtin_nontemporal_load(pb + q);
+        R.cv[j] = __builtin_nontemporal_load(pc + q);
       }
     } else if (j < ROUNDS - 1 || q < SN) {
-      R.av[j] = __builtin_nontemporal_load(a + i);
-      R.bv[j] = __builtin_nontemporal_load(b + ki);
-      R.cv[j] = __builtin_nontemporal_load(c + ki);
+      R.av[j] = __builtin_nontemporal_load(pa + q);
+      R.bv[j] = __builtin_nontemporal_load(pb + q);
+      R.cv[j] = __builtin_nontemporal_load(pc + q);
     }
   }
 #pragma unroll
   for (int r = 0; r < EB; ++r) {
-    const long i = base + t + r * T;
+    const int e = t + r * T;
     R.Gv[r] = make_float2(0.f, 0.f);
     R.gv[r] = make_float2(0.f, 0.f);
-    if (!CHECK || i < N) {
-      R.Gv[r] = ld2(G + 2 * i);
-      if (gf) R.gv[r] = ld2(gf + 2 * i);
+    if (!CHECK || e < ig1) {
+      R.Gv[r] = ld2(pG + 2 * e);
+      if (pg) R.gv[r] = ld2(pg + 2 * e);
     }
   }
 }
-template <int OFF, bool THETA>
 __device__ __forceinline__ void issue_chunk(const float *__restrict__ a, const float *__restrict__ b,
                                             const float *__restrict__ c, const float *__restrict__ G,
-                                            const float *__restrict__ gf, long base, long N, Raw &R) {
-  if (base - WH - 1 >= 0 && base + CHUNK + WH - 1 <= N - 2) issue_loads<OFF, THETA, false>(a, b, c, G, gf, base, N, R);
-  else issue_loads<OFF, THETA, true>(a, b, c, G, gf, base, N, R);
+                                            const float *__restrict__ gf, long base, long N, Raw &R, int t) {
+  if (base - WH - 1 >= 0 && base + CHUNK + WH - 1 <= N - 1) issue_loads<false>(a, b, c, G, gf, base, N, R, t);
+  else issue_loads<true>(a, b, c, G, gf, base, N, R, t);
 }
 
 // Writes a chunk's staged form: regularised diagonal and off-diagonal products with their halo, q, and for the
-// lanes' output pass the raw diagonal (and, in the theta phase, b and c) of the chunk's own elements.
-template <bool THETA>
+// lanes' output pass the raw diagonal, b and c of the chunk's own elements.
 __device__ __forceinline__ void commit_chunk(const Raw &R, const float *__restrict__ gG, long base, long N, float2 z,
-                                             SharedSweep &sh) {
-  const int t = threadIdx.x;
+                                             SharedSweep &sh, int t) {
 #pragma unroll
   for (int j = 0; j < ROUNDS; ++j) {
     const int q = t + j * T;
@@ -632,14 +640,14 @@ __device__ __forceinline__ void commit_chunk(const Raw &R, const float *__restri
       sh.al_s[q + q / EB] = reg_diag(R.av[j], z);
       const int e = q - WH;
       if (e >= 0 && e < CHUNK) sh.a_s[e + e / EB] = R.av[j];
-      if (THETA && e >= 1 && e <= CHUNK) sh.bc_s[(e - 1) + (e - 1) / EB] = make_float2(R.bv[j], R.cv[j]);
+      if (e >= 1 && e <= CHUNK) sh.bc_s[(e - 1) + (e - 1) / EB] = make_float2(R.bv[j], R.cv[j]);
     }
   }
 #pragma unroll
   for (int r = 0; r < EB; ++r) {
     const int e = t + r * T;
     float2 g = R.gv[r];
-    if (gG && base + e < N) g = cadd(g, ld2(gG + 2 * (base + e)));
+    if (gG && e < N - base) g = cadd(g, ld2(gG + 2 * base + 2 * e));
     // a cotangent that is not a number counts as 0, as in the reference's backward (bk_core.py:321-325)
     const float gx = fabsf(g.x) <= 3.0e38f ? g.x : 0.0f;
     const float gy = fabsf(g.y) <= 3.0e38f ? g.y : 0.0f;
@@ -654,219 +662,9 @@ __device__ __forceinline__ float2 adj_step(float2 x, float2 cw, float2 inv, floa
   return cmul(inv, u);
 }
 
-template <int OFF, bool THETA>
-__device__ __forceinline__ void sweep_phase(const float *__restrict__ a, const float *__restrict__ b,
-                                            const float *__restrict__ c, const float *__restrict__ G,
-                                            const float *__restrict__ gf, const float *__restrict__ gG,
-                                            float *__restrict__ ga, float *__restrict__ gb, float *__restrict__ gc,
-                                            long N, float2 z, float2 Q, SharedSweep &sh, bool &bad, int &par,
-                                            unsigned long long *dbg) {
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int nch = (int)((N + CHUNK - 1) / CHUNK);
-  const int seg = THETA ? T - 1 - t : t;  // theta: descending segments over ascending threads
-  if (t == 0) {
-    sh.sumcarry[par & 1] = make_float2(0.f, 0.f);
-    sh.xedge[(par & 1) ^ 1][WAVES - 1][0] = make_float4(0.f, 0.f, 0.f, 0.f);
-    sh.xedge[(par & 1) ^ 1][WAVES - 1][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  Raw R;
-  if (BK_SWEEP_PREFETCH) issue_chunk<OFF, THETA>(a, b, c, G, gf, (long)(THETA ? nch - 1 : 0) * CHUNK, N, R);
-  for (int cc = 0; cc < nch; ++cc, ++par) {
-    const int ch = THETA ? nch - 1 - cc : cc;
-    const int buf = par & 1;
-    const long base = (long)ch * CHUNK;
-    const long first = base + (long)seg * EB;
-    BK_SSTAMP(0);
-    if (!BK_SWEEP_PREFETCH) issue_chunk<OFF, THETA>(a, b, c, G, gf, base, N, R);
-    __syncthreads();  // every lane finished reading the staging area
-    commit_chunk<THETA>(R, gG, base, N, z, sh);
-    __syncthreads();
-    BK_SSTAMP(1);
-    const float2 *al_l = sh.al_s + (WH + seg * EB) + (WH + seg * EB) / EB;
-    const float *k_l = sh.k_s + (WH + seg * EB) + (WH + seg * EB) / EB;
-    const float2 *q_l = sh.q_s + seg * (EB + 1);
-    // What the lane's chains read from the staging area is loaded in batches, each one issued before the arithmetic on
-    // the batch before it.  Ratio chain: warm-up over the WH elements before the lane's own in the direction of the
-    // recurrence (past the end of the row the staged values give om * 0), then the lane's own.
-    float2 alw[WH], alo[EB], q[EB], inv[EB];
-    float kw[WH], ko[EB], kx, wc[EB], tau[EB];
-    float2 om = make_float2(0.f, 0.f);
-    float lmin = 0.0f;
-#pragma unroll
-    for (int j = 0; j < WH / 2; ++j) {
-      const int d = THETA ? j - WH : EB + WH - 1 - j;
-      alw[j] = al_l[soff(d)];
-      kw[j] = k_l[soff(d)];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = WH / 2; j < WH; ++j) {
-      const int d = THETA ? j - WH : EB + WH - 1 - j;
-      alw[j] = al_l[soff(d)];
-      kw[j] = k_l[soff(d)];
-    }
-#pragma unroll
-    for (int j = 0; j < WH / 2; ++j) om = om_coarse(alw[j], kw[j], om);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int e = 0; e < EB; ++e) {
-      alo[e] = al_l[soff(e)];
-      ko[e] = k_l[soff(e)];
-      q[e] = q_l[e];
-    }
-    kx = k_l[soff(THETA ? EB : -1)];
-#pragma unroll
-    for (int j = WH / 2; j < WH; ++j) {
-      if (j < 3 * WH / 4) om = om_short(alw[j], kw[j], om);
-      else {
-        float2 iv;
-        float wv, tv, lv = 0.0f;
-        om = om_full(alw[j], kw[j], om, iv, wv, tv, lv);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const float2 west = om;
-#pragma unroll
-    for (int j = 0; j < EB; ++j) {
-      const int e = THETA ? j : EB - 1 - j;
-      om = om_full(alo[e], ko[e], om, inv[e], wc[e], tau[e], lmin);
-    }
-    float2 sum = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int e = 0; e < EB; ++e) sum = cadd(sum, q[e]);
-    // the off-diagonal product of the adjoint step at element e: theta k_j = slot e + 1, phi kphi_{j-1} = slot e - 1
-    float kk[EB];
-#pragma unroll
-    for (int e = 0; e < EB; ++e) kk[e] = THETA ? (e + 1 < EB ? ko[e + 1 < EB ? e + 1 : 0] : kx) : (e >= 1 ? ko[e >= 1 ? e - 1 : 0] : kx);
-    if (THETA && base + CHUNK > N) {  // lam = 0 enters the last element: elements past it map everything to 0
-#pragma unroll
-      for (int e = 0; e < EB; ++e)
-        if (first + e >= N) inv[e] = make_float2(0.f, 0.f);
-    }
-    // lane sums of q -> exclusive prefix in thread order
-    float2 incl = sum;
-    incl = cadd(incl, sum_dpp<0x111, 0xF>(incl));
-    incl = cadd(incl, sum_dpp<0x112, 0xF>(incl));
-    incl = cadd(incl, sum_dpp<0x114, 0xF>(incl));
-    incl = cadd(incl, sum_dpp<0x118, 0xF>(incl));
-    incl = cadd(incl, sum_dpp<0x142, 0xA>(incl));
-    incl = cadd(incl, sum_dpp<0x143, 0xC>(incl));
-    if (lane == 63) {
-      sh.sumtot[buf][wave] = incl;
-      sh.wedge[buf][wave] = west;
-    }
-    if (t == T - 1) sh.edge[buf] = west;
-    float2 run = sum_dpp<0x138, 0xF>(incl);  // wave_shr:1
-    float2 nb = sum_dpp<0x138, 0xF>(west);
-    BK_SSTAMP(2);
-    __syncthreads();
-    BK_SSTAMP(3);
-    {
-      float2 x = sh.sumcarry[buf];
-#pragma unroll
-      for (int w = 0; w < WAVES; ++w) {
-        if (w == wave) run = cadd(run, x);
-        x = cadd(x, sh.sumtot[buf][w]);
-      }
-      if (t == 0) sh.sumcarry[buf ^ 1] = x;
-      // the previous lane's warm-up ran over this lane's elements: both must agree on om after the lane's last step
-      if (lane == 0) nb = wave > 0 ? sh.wedge[buf][wave - 1] : sh.edge[buf ^ 1];
-      const bool have_nb = (t > 0 || cc > 0) && (THETA ? first + EB < N : first < N);
-      if (have_nb) bad |= om_differs(nb, om);
-      if (first < N) bad |= !(lmin >= -13.3f);
-    }
-    // the next chunk's raw values travel while the adjoint chains of this one run
-    if (BK_SWEEP_PREFETCH && cc + 1 < nch) issue_chunk<OFF, THETA>(a, b, c, G, gf, base + (THETA ? -CHUNK : CHUNK), N, R);
-    float gav[EB], gkp[EB];
-    if (THETA) {  // what the first phase left in the output buffers
-      load_block<EB>(ga, first, 0, N, 0.0f, gav);
-      if (gb) load_block<EB>(gb, first, 0, N - 1 - OFF, 0.0f, gkp);
-    }
-    // the lane's maps applied to 0, and the product of their linear parts
-    float2 v = make_float2(0.f, 0.f), m = make_float2(1.f, 0.f);
-    {
-      float2 r2 = run;
-#pragma unroll
-      for (int j = 0; j < EB; ++j) {
-        const int e = THETA ? EB - 1 - j : j;
-        const float g = kk[e] * wc[e];
-        const float2 cw = make_float2(inv[e].x * g, inv[e].y * g);
-        // phi: c0 = P_{j-1};  theta: c0 = -P_j = (sum of q to the right of j) - total
-        const float2 c0 = THETA ? make_float2(r2.x - Q.x, r2.y - Q.y) : r2;
-        v = adj_step(v, cw, inv[e], tau[e], c0);
-        m = cmul(m, cmul(inv[e], cw));
-        r2 = cadd(r2, q[e]);
-      }
-    }
-    if (lane >= 62) sh.xedge[buf][wave][lane - 62] = make_float4(v.x, v.y, m.x, m.y);
-    float2 v1 = sum_dpp<0x138, 0xF>(v), m1 = sum_dpp<0x138, 0xF>(m);
-    BK_SSTAMP(4);
-    __syncthreads();
-    BK_SSTAMP(5);
-    if (lane == 0) {
-      const float4 s1 = wave > 0 ? sh.xedge[buf][wave - 1][1] : sh.xedge[buf ^ 1][WAVES - 1][1];
-      v1 = make_float2(s1.x, s1.y);
-      m1 = make_float2(s1.z, s1.w);
-    }
-    float2 v2 = sum_dpp<0x138, 0xF>(v1), m2 = sum_dpp<0x138, 0xF>(m1);
-    if (lane == 0) {
-      const float4 s2 = wave > 0 ? sh.xedge[buf][wave - 1][0] : sh.xedge[buf ^ 1][WAVES - 1][0];
-      v2 = make_float2(s2.x, s2.y);
-      m2 = make_float2(s2.z, s2.w);
-    }
-    float2 x = cadd(v1, cmul(m1, v2));
-    bad |= !(fmaf(m1.x, m1.x, m1.y * m1.y) * fmaf(m2.x, m2.x, m2.y * m2.y) <= 4.0e-10f);
-    const float *a_l = sh.a_s + seg * (EB + 1);
-    const float2 *bc_l = sh.bc_s + seg * (EB + 1);
-    float ao[EB];
-    float2 bco[EB];
-#pragma unroll
-    for (int e = 0; e < EB; ++e) {
-      ao[e] = a_l[e];
-      if (THETA) bco[e] = bc_l[e];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    float gkv[EB];
-    {
-      float2 r2 = run;
-#pragma unroll
-      for (int j = 0; j < EB; ++j) {
-        const int e = THETA ? EB - 1 - j : j;
-        const float g = kk[e] * wc[e];
-        const float2 w = make_float2(inv[e].x * wc[e], inv[e].y * wc[e]);
-        const float2 cw = make_float2(inv[e].x * g, inv[e].y * g);
-        const float2 c0 = THETA ? make_float2(r2.x - Q.x, r2.y - Q.y) : r2;
-        const float gk = -fmaf(x.x, w.x, -x.y * w.y);
-        x = adj_step(x, cw, inv[e], tau[e], c0);
-        r2 = cadd(r2, q[e]);
-        const float da = times_dreg(x, ao[e], z);
-        if (THETA) {
-          gav[e] = finite_or_zero(gav[e] + da);
-          if (gb) {
-            const float gt = gkp[e] + gk;
-            const float2 bc = bco[e];
-            gkv[e] = finite_or_zero(bc.y * gt);
-            gkp[e] = finite_or_zero(bc.x * gt);
-          }
-        } else {
-          gav[e] = da;
-          gkv[e] = gk;
-        }
-      }
-    }
-    BK_SSTAMP(6);
-    store_block<EB>(ga, first, 0, N, gav);
-    if (gb) {
-      if (THETA) {
-        store_block<EB>(gb, first, 0, N - 1, gkv);
-        store_block<EB>(gc, first, 0, N - 1, gkp);
-      } else {
-        // element j >= 1 wrote the phi part of grad_k at index j - 1 - OFF (0 from j = 1: mu_0 = 0)
-        store_block<EB>(gb, first - 1 - OFF, 0, N - 1 - OFF, gkv);
-      }
-    }
-    BK_SSTAMP(7);
-  }
+template <int CTRL>
+__device__ __forceinline__ float2 shift2(float2 v) {  // lane shift by DPP, 0 where there is no source lane
+  return make_float2(dpp_f<CTRL, 0xF>(0.0f, v.x), dpp_f<CTRL, 0xF>(0.0f, v.y));
 }
 
 template <int OFF>  // kphi_m = k_{m-OFF}
@@ -885,13 +683,303 @@ __global__ __launch_bounds__(T, BK_SWEEP_WG) void bk_adjoint_sweeps(
   float *gb = gb_ ? gb_ + row * (N - 1) : nullptr;
   float *gc = gc_ ? gc_ + row * (N - 1) : nullptr;
   const float2 z = z_dev ? make_float2(z_dev[0], z_dev[1]) : make_float2(z_re, z_im);
+  const int t = threadIdx.x;
+  const int nch = N <= CHUNK ? 1 : 1 + (int)((N - CHUNK + STRIDE - 1) / STRIDE);
   bool bad = false;
-  int par = 0;
-  sweep_phase<OFF, false>(a, b, c, G, gf, gG, ga, gb, gc, N, z, make_float2(0.f, 0.f), sh, bad, par, dbg);
-  __syncthreads();
-  const float2 Q = sh.sumcarry[par & 1];  // sum of q over the row
-  __syncthreads();
-  sweep_phase<OFF, true>(a, b, c, G, gf, gG, ga, gb, gc, N, z, Q, sh, bad, par, dbg);
+  if (t == 0) {
+    sh.sumcarry[0] = make_float2(0.f, 0.f);
+    sh.xc_p[1][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    sh.xc_p[1][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  Raw R;
+  if (BK_SWEEP_PREFETCH) issue_chunk(a, b, c, G, gf, 0, N, R, t);
+  for (int cc = 0; cc < nch; ++cc) {
+    const int buf = cc & 1;
+    const long base = (long)cc * STRIDE;
+    const bool tail = base + CHUNK + WH >= N - 1;  // the end of the row lies in what this chunk stages
+    BK_SSTAMP(0);
+    // (the thread index goes through an opaque copy at each stage: offsets derived from it are then recomputed where
+    // they are used instead of being kept in registers across the whole loop)
+    int ts = t;
+    asm volatile("" : "+v"(ts));
+    if (!BK_SWEEP_PREFETCH) issue_chunk(a, b, c, G, gf, base, N, R, ts);
+    __syncthreads();  // every lane finished reading the staging area
+    commit_chunk(R, gG, base, N, z, sh, ts);
+    __syncthreads();
+    BK_SSTAMP(1);
+    __builtin_amdgcn_sched_barrier(0);
+    int tl = t;
+    asm volatile("" : "+v"(tl));
+    const long first = base + (long)tl * EB;
+    const float2 *al_l = sh.al_s + (WH + tl * EB) + (WH + tl * EB) / EB;
+    const float *k_l = sh.k_s + (WH + tl * EB) + (WH + tl * EB) / EB;
+    const float2 *q_l = sh.q_s + tl * (EB + 1);
+    // What the lane's chains read from the staging area is loaded in batches, each one issued before the arithmetic on
+    // the batch before it.  Ratio chains: warm-up over the WH elements before the lane's own in the direction of the
+    // recurrence (theta: to the left; phi: to the right, where past the end of the row the staged values give om * 0),
+    // then the lane's own.  kphi_d = k_{d-OFF} sits in slot d + 1 - OFF and is 0 from the last element on.
+    float2 alt[WH], alp[WH], alo[EB];
+    float kt[WH], kp[WH], kx[EB + 2];  // kx[x] = slot x - 1
+    float2 omt = make_float2(0.f, 0.f), omp = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < WH / 2; ++j) {
+      alt[j] = al_l[soff(j - WH)];
+      kt[j] = k_l[soff(j - WH)];
+      alp[j] = al_l[soff(EB + WH - 1 - j)];
+      kp[j] = k_l[soff(EB + WH - j - OFF)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = WH / 2; j < WH; ++j) {
+      alt[j] = al_l[soff(j - WH)];
+      kt[j] = k_l[soff(j - WH)];
+      alp[j] = al_l[soff(EB + WH - 1 - j)];
+      kp[j] = k_l[soff(EB + WH - j - OFF)];
+    }
+    if (tail) {
+#pragma unroll
+      for (int j = 0; j < WH / 2; ++j)
+        if (first + (EB + WH - 1 - j) >= N - 1) kp[j] = 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < WH / 2; ++j) {
+      omt = om_coarse(alt[j], kt[j], omt);
+      omp = om_coarse(alp[j], kp[j], omp);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < EB; ++e) alo[e] = al_l[soff(e)];
+#pragma unroll
+    for (int x = 0; x < EB + 2; ++x) kx[x] = k_l[soff(x - 1)];
+    if (tail) {
+#pragma unroll
+      for (int j = WH / 2; j < WH; ++j)
+        if (first + (EB + WH - 1 - j) >= N - 1) kp[j] = 0.0f;
+    }
+    float2 inv8 = make_float2(0.f, 0.f), om9 = make_float2(0.f, 0.f);  // phi at elements 8 and 9 of the lane
+    float wc8 = 0.0f, tau8 = 0.0f;
+#pragma unroll
+    for (int j = WH / 2; j < WH; ++j) {
+      if (j < 3 * WH / 4) {
+        omt = om_short(alt[j], kt[j], omt);
+        omp = om_short(alp[j], kp[j], omp);
+      } else {
+        float2 iv;
+        float wv, tv, lv = 0.0f;
+        omt = om_full(alt[j], kt[j], omt, iv, wv, tv, lv);
+        if (j == WH - 1) om9 = omp;
+        omp = om_full(alp[j], kp[j], omp, inv8, wc8, tau8, lv);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float2 q[EB];
+#pragma unroll
+    for (int e = 0; e < EB; ++e) q[e] = q_l[e];
+    const float2 west_t = omt, west_p = omp;
+    float2 invt[EB], invp[EB];
+    float wct[EB], taut[EB], wcp[EB], taup[EB];
+    float lmin = 0.0f;
+#pragma unroll
+    for (int j = 0; j < EB; ++j) {
+      const int et = j, ep = EB - 1 - j;
+      float kpe = kx[ep + 2 - OFF];
+      if (tail && first + ep >= N - 1) kpe = 0.0f;
+      omt = om_full(alo[et], kx[et + 1], omt, invt[et], wct[et], taut[et], lmin);
+      omp = om_full(alo[ep], kpe, omp, invp[ep], wcp[ep], taup[ep], lmin);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (tail) {  // elements past the end of the row map everything to 0 (lam = 0 enters the last element)
+#pragma unroll
+      for (int e = 0; e < EB; ++e)
+        if (first + e >= N) {
+          invt[e] = make_float2(0.f, 0.f);
+          invp[e] = make_float2(0.f, 0.f);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // exclusive prefix sums of q inside the lane, then over the lanes
+    float2 pre[EB + 1];
+    pre[0] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int e = 0; e < EB; ++e) pre[e + 1] = cadd(pre[e], q[e]);
+    float2 incl = pre[EB];
+    incl = cadd(incl, sum_dpp<0x111, 0xF>(incl));
+    incl = cadd(incl, sum_dpp<0x112, 0xF>(incl));
+    incl = cadd(incl, sum_dpp<0x114, 0xF>(incl));
+    incl = cadd(incl, sum_dpp<0x118, 0xF>(incl));
+    incl = cadd(incl, sum_dpp<0x142, 0xA>(incl));
+    incl = cadd(incl, sum_dpp<0x143, 0xC>(incl));
+    __builtin_amdgcn_sched_barrier(0);
+    const int lane = tl & 63, wave = tl >> 6;
+    if (lane == 63) {
+      sh.sumtot[buf][wave] = incl;
+      sh.wedge_t[buf][wave] = omt;
+      sh.wedge_p[buf][wave] = west_p;
+    }
+    if (tl == T - 1 - HALO_LANES) {
+      sh.edge_t[buf] = omt;
+      sh.edge_p[buf] = west_p;
+    }
+    float2 run = shift2<0x138>(incl);  // wave_shr:1
+    float2 nb_t = shift2<0x138>(omt), nb_p = shift2<0x138>(west_p);
+    BK_SSTAMP(2);
+    __syncthreads();
+    BK_SSTAMP(3);
+    {
+      float2 x = sh.sumcarry[buf];
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) {
+        if (w == wave) run = cadd(run, x);
+        x = cadd(x, sh.sumtot[buf][w]);
+      }
+      if (tl == T - 1 - HALO_LANES) sh.sumcarry[buf ^ 1] = cadd(run, pre[EB]);  // sum up to the next chunk's start
+      // the left neighbour's last own step (theta) / warm-up (phi) and this lane's warm-up (theta) / first own step
+      // (phi) are two evaluations of the same om
+      if (lane == 0) {
+        nb_t = wave > 0 ? sh.wedge_t[buf][wave - 1] : sh.edge_t[buf ^ 1];
+        nb_p = wave > 0 ? sh.wedge_p[buf][wave - 1] : sh.edge_p[buf ^ 1];
+      }
+      if ((tl > 0 || cc > 0) && first < N) bad |= om_differs(west_t, nb_t) || om_differs(nb_p, omp);
+      if (first < N) bad |= !(lmin >= -13.3f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e <= EB; ++e) pre[e] = cadd(pre[e], run);  // pre[e] = P_{first + e - 1}
+    if (BK_SWEEP_PREFETCH && cc + 1 < nch) issue_chunk(a, b, c, G, gf, base + STRIDE, N, R, tl);
+    __builtin_amdgcn_sched_barrier(0);
+    // the lane's maps applied to 0 and the product of their linear parts, for both adjoints:
+    //   mu  (left -> right): c0 = P_{j-1},  off-diagonal product kphi_{j-1} = slot e - OFF
+    //   lam (right -> left): c0 = -P_j,     off-diagonal product k_j        = slot e + 1
+    float2 vp = make_float2(0.f, 0.f), mp = make_float2(1.f, 0.f);
+    float2 vt = make_float2(0.f, 0.f), mt = make_float2(1.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < EB; ++j) {
+      const int ep = j, et = EB - 1 - j;
+      const float gp = kx[ep + 1 - OFF] * wcp[ep], gt = kx[et + 2] * wct[et];
+      const float2 cwp = make_float2(invp[ep].x * gp, invp[ep].y * gp);
+      const float2 cwt = make_float2(invt[et].x * gt, invt[et].y * gt);
+      vp = adj_step(vp, cwp, invp[ep], taup[ep], pre[ep]);
+      vt = adj_step(vt, cwt, invt[et], taut[et], make_float2(-pre[et + 1].x, -pre[et + 1].y));
+      mp = cmul(mp, cmul(invp[ep], cwp));
+      mt = cmul(mt, cmul(invt[et], cwt));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      int tv = t;
+      asm volatile("" : "+v"(tv));
+      const int lv = tv & 63, wv = tv >> 6;
+      if (lv >= 62) sh.xe_p[buf][wv][lv - 62] = make_float4(vp.x, vp.y, mp.x, mp.y);
+      if (lv <= 1) sh.xe_t[buf][wv][lv] = make_float4(vt.x, vt.y, mt.x, mt.y);
+      if (tv >= T - 2 - HALO_LANES && tv < T - HALO_LANES)
+        sh.xc_p[buf][tv - (T - 2 - HALO_LANES)] = make_float4(vp.x, vp.y, mp.x, mp.y);
+    }
+    float2 vp1 = shift2<0x138>(vp), mp1 = shift2<0x138>(mp);  // wave_shr:1
+    float2 vt1 = shift2<0x130>(vt), mt1 = shift2<0x130>(mt);  // wave_shl:1
+    BK_SSTAMP(4);
+    __syncthreads();
+    BK_SSTAMP(5);
+    int to = t;
+    asm volatile("" : "+v"(to));
+    const int lo = to & 63, wo = to >> 6;
+    if (lo == 0) {
+      const float4 s1 = wo > 0 ? sh.xe_p[buf][wo - 1][1] : sh.xc_p[buf ^ 1][1];
+      vp1 = make_float2(s1.x, s1.y);
+      mp1 = make_float2(s1.z, s1.w);
+    }
+    if (lo == 63) {
+      const float4 s1 = wo < WAVES - 1 ? sh.xe_t[buf][wo < WAVES - 1 ? wo + 1 : 0][0]
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      vt1 = make_float2(s1.x, s1.y);
+      mt1 = make_float2(s1.z, s1.w);
+    }
+    float2 vp2 = shift2<0x138>(vp1), mp2 = shift2<0x138>(mp1);
+    float2 vt2 = shift2<0x130>(vt1), mt2 = shift2<0x130>(mt1);
+    if (lo == 0) {
+      const float4 s2 = wo > 0 ? sh.xe_p[buf][wo - 1][0] : sh.xc_p[buf ^ 1][0];
+      vp2 = make_float2(s2.x, s2.y);
+      mp2 = make_float2(s2.z, s2.w);
+    }
+    if (lo == 63) {
+      const float4 s2 = wo < WAVES - 1 ? sh.xe_t[buf][wo < WAVES - 1 ? wo + 1 : 0][1]
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      vt2 = make_float2(s2.x, s2.y);
+      mt2 = make_float2(s2.z, s2.w);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float2 xp = cadd(vp1, cmul(mp1, vp2));  // mu_{first-1} / s_{first-1}
+    float2 xt = cadd(vt1, cmul(mt1, vt2));  // lam_{first+8} / r_{first+8}
+    bad |= !(fmaf(mp1.x, mp1.x, mp1.y * mp1.y) * fmaf(mp2.x, mp2.x, mp2.y * mp2.y) <= 4.0e-10f);
+    bad |= !(fmaf(mt1.x, mt1.x, mt1.y * mt1.y) * fmaf(mt2.x, mt2.x, mt2.y * mt2.y) <= 4.0e-10f);
+    __builtin_amdgcn_sched_barrier(0);
+    // output pass: xs = lam_j / r_j + mu_j / s_j;  gk[e] = gradient with respect to k_{first+e}: the theta part comes
+    // from element e, the phi part from element e + 1 + OFF (elements 8 and 9 lie in the next lane's block: one or
+    // two more steps of mu through the values the phi warm-up ended on)
+    float2 xs[EB];
+    float gk[EB];
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+      xs[e] = make_float2(0.f, 0.f);
+      gk[e] = 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < EB; ++j) {
+      const int ep = j, et = EB - 1 - j;
+      const float gp = kx[ep + 1 - OFF] * wcp[ep], gt = kx[et + 2] * wct[et];
+      const float2 wp = make_float2(invp[ep].x * wcp[ep], invp[ep].y * wcp[ep]);
+      const float2 wt = make_float2(invt[et].x * wct[et], invt[et].y * wct[et]);
+      const float2 cwp = make_float2(invp[ep].x * gp, invp[ep].y * gp);
+      const float2 cwt = make_float2(invt[et].x * gt, invt[et].y * gt);
+      if (ep - 1 - OFF >= 0) gk[ep - 1 - OFF >= 0 ? ep - 1 - OFF : 0] -= fmaf(xp.x, wp.x, -xp.y * wp.y);
+      gk[et] -= fmaf(xt.x, wt.x, -xt.y * wt.y);
+      xp = adj_step(xp, cwp, invp[ep], taup[ep], pre[ep]);
+      xt = adj_step(xt, cwt, invt[et], taut[et], make_float2(-pre[et + 1].x, -pre[et + 1].y));
+      xs[ep] = cadd(xs[ep], xp);
+      xs[et] = cadd(xs[et], xt);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(to));
+    const float *a_l = sh.a_s + to * (EB + 1);
+    const float2 *bc_l = sh.bc_s + to * (EB + 1);
+    float ao[EB];
+    float2 bco[EB];
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+      ao[e] = a_l[e];
+      bco[e] = bc_l[e];
+    }
+    {
+      // element 8: w(s_8) is what the phi warm-up ended on; element 9 (OFF = 1): one more step of mu through 8
+      const float2 w8 = make_float2(inv8.x * wc8, inv8.y * wc8);
+      float g8 = -fmaf(xp.x, w8.x, -xp.y * w8.y);
+      if (!(first + EB - 1 - OFF < N - 1 - OFF)) g8 = 0.0f;
+      gk[EB - 1 - OFF] += g8;
+      if (OFF == 1) {
+        const float g = kx[EB + 1 - OFF] * wc8;
+        const float2 cw = make_float2(inv8.x * g, inv8.y * g);
+        xp = adj_step(xp, cw, inv8, tau8, pre[EB]);
+        float g9 = -fmaf(xp.x, om9.x, -xp.y * om9.y);
+        if (!(first + EB - 1 < N - 1 - OFF)) g9 = 0.0f;
+        gk[EB - 1] += g9;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float gav[EB], gbv[EB], gcv[EB];
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+      gav[e] = finite_or_zero(times_dreg(xs[e], ao[e], z));
+      gbv[e] = finite_or_zero(bco[e].y * gk[e]);
+      gcv[e] = finite_or_zero(bco[e].x * gk[e]);
+    }
+    BK_SSTAMP(6);
+    if (cc == nch - 1 || to < T - HALO_LANES) {
+      store_block<EB>(ga + base, to * EB, 0, N - base, gav);
+      if (gb) {
+        store_block<EB>(gb + base, to * EB, 0, N - 1 - base, gbv);
+        store_block<EB>(gc + base, to * EB, 0, N - 1 - base, gcv);
+      }
+    }
+    BK_SSTAMP(7);
+  }
   const int any_bad = __syncthreads_or(bad ? 1 : 0);
   if (threadIdx.x == 0) {
     rowbad[row] = any_bad;

@@ -41,5 +41,8 @@ for want_bc in (True, False):
         bkcore.bk_backward_analytic(a, b, c, 1j, gf, None, want_bc=want_bc, G=G)
     e1.record(); torch.cuda.synchronize()
     out.append(e0.elapsed_time(e1) / args.reps)
+bkcore.bk_core._DEBUG["keep_ws"] = True
+bkcore.bk_backward_analytic(a, b, c, 1j, gf, None, G=G)
+nre = bkcore.bk_core.analytic_rows_recomputed()
 st = bkcore.bk_core._state_block(a.device, torch.cuda.current_stream().cuda_stream) if hasattr(bkcore.bk_core, "_state_block") else None
-print(f"{tag:34s} err {worst:.1e}  bwd {out[0]:.3f} ms  (a only {out[1]:.3f} ms)  state {st[:8].tolist() if st is not None else None}", flush=True)
+print(f"{tag:34s} err {worst:.1e}  bwd {out[0]:.3f} ms  (a only {out[1]:.3f} ms)  rows recomputed {nre}", flush=True)

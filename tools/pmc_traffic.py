@@ -20,9 +20,14 @@ for (name, ctr), v in sorted(agg.items()):
 fetch = summ.get("bk_ratio_forward_kernel|FETCH_SIZE", {}).get("mean_KiB", 0.0)
 write = summ.get("bk_ratio_forward_kernel|WRITE_SIZE", {}).get("mean_KiB", 0.0)
 total = (2.0 * fetch + write) * 1024.0
+afetch = summ.get("bk_adjoint_sweeps|FETCH_SIZE", {}).get("mean_KiB", 0.0)
+awrite = summ.get("bk_adjoint_sweeps|WRITE_SIZE", {}).get("mean_KiB", 0.0)
+atotal = (2.0 * afetch + awrite) * 1024.0
 res = {"counters": summ,
        "note": "FETCH_SIZE on gfx950 reports half the bytes of wide coalesced reads; doubled. WRITE_SIZE is exact.",
        "forward_traffic_bytes_per_launch_corrected": total,
-       "forward_traffic_bytes_per_elem_corrected": total / (B * N)}
+       "forward_traffic_bytes_per_elem_corrected": total / (B * N),
+       "analytic_traffic_bytes_per_launch_corrected": atotal,
+       "analytic_traffic_bytes_per_elem_corrected": atotal / (B * N)}
 json.dump(res, open(out_path, "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("forward_traffic_bytes_per_launch_corrected", "forward_traffic_bytes_per_elem_corrected")}))
