@@ -17,11 +17,17 @@ from .layers import BKCoreLayer
 
 
 class ResNetBKBlock(nn.Module):
-    def __init__(self, d_model: int, n_seq: int, ffn_mult: int = 4, fused: bool = False):
+    """``ffn_mult = 2, ffn_activation = "relu"`` is the reference's feed-forward branch with a single expert
+    (src/models/moe.py:61-69 with num_experts = 1: the softmax over one gate is 1, so the layer is its one expert)."""
+
+    def __init__(self, d_model: int, n_seq: int, ffn_mult: int = 4, fused: bool = False, ffn_activation: str = "gelu"):
         super().__init__()
+        if ffn_activation not in ("gelu", "relu"):
+            raise ValueError(f"unknown ffn_activation {ffn_activation!r}")
         self.layer_norm = nn.LayerNorm(d_model)
         self.bk_layer = BKCoreLayer(d_model, n_seq, fused=fused)
-        self.ffn = nn.Sequential(nn.Linear(d_model, ffn_mult * d_model), nn.GELU(), nn.Linear(ffn_mult * d_model, d_model))
+        act = nn.GELU() if ffn_activation == "gelu" else nn.ReLU()
+        self.ffn = nn.Sequential(nn.Linear(d_model, ffn_mult * d_model), act, nn.Linear(ffn_mult * d_model, d_model))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         h = self.layer_norm(x)
@@ -32,12 +38,13 @@ class ResNetBKBlock(nn.Module):
 
 class SmallResNetBKLM(nn.Module):
     def __init__(self, vocab_size: int = 50257, d_model: int = 256, n_layers: int = 4, n_seq: int = 256,
-                 fused: bool = False):
+                 fused: bool = False, ffn_mult: int = 4, ffn_activation: str = "gelu"):
         super().__init__()
         self.n_seq = n_seq
         self.token_embedding = nn.Embedding(vocab_size, d_model)
         self.position_embedding = nn.Embedding(n_seq, d_model)
-        self.blocks = nn.ModuleList([ResNetBKBlock(d_model, n_seq, fused=fused) for _ in range(n_layers)])
+        self.blocks = nn.ModuleList([ResNetBKBlock(d_model, n_seq, ffn_mult=ffn_mult, fused=fused,
+                                                   ffn_activation=ffn_activation) for _ in range(n_layers)])
         self.layer_norm_final = nn.LayerNorm(d_model)
         self.lm_head = nn.Linear(d_model, vocab_size)
         nn.init.normal_(self.token_embedding.weight, std=0.02)
@@ -52,6 +59,7 @@ class SmallResNetBKLM(nn.Module):
         B, N = tokens.shape
         pos = torch.arange(N, device=tokens.device)
         x = self.token_embedding(tokens) + self.position_embedding(pos)[None]
+        x = torch.clamp(torch.nan_to_num(x, nan=0.0, posinf=10.0, neginf=-10.0), -10.0, 10.0)  # resnet_bk.py:469-470
         for blk in self.blocks:
             x = blk(x)
         return self.lm_head(self.layer_norm_final(x))
