@@ -97,6 +97,14 @@ size_t bkcore_workspace_bytes(int64_t B, int64_t N);
  */
 int bkcore_backward_ref(const float *G, const float *grad_features, const float *grad_G, float alpha, int64_t n,
                         float *grad_a, void *stream);
+/*
+ * The same, and *nonfinite_flag (one int in device memory, may be NULL) is set to 1 when grad_features holds a NaN or
+ * an infinity -- the condition under which the reference warns (src/models/bk_core.py:321-325) before it replaces
+ * them.  The flag is only ever raised: the caller clears it and reads it back when it wishes (no host
+ * synchronisation inside the call).
+ */
+int bkcore_backward_ref_flagged(const float *G, const float *grad_features, const float *grad_G, float alpha, int64_t n,
+                                float *grad_a, int *nonfinite_flag, void *stream);
 
 /*
  * Backward, analytic mode: the gradient of L with respect to he_diag, h0_super and h0_sub, where

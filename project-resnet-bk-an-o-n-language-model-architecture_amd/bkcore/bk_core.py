@@ -190,8 +190,44 @@ def rows_recomputed():
     return int(ws[: 4 * B].view(torch.int32).ne(0).sum().item())
 
 
-def bk_backward_reference(G, grad_features, grad_G, alpha: float):
-    """Launch the reference-mode backward kernel.  Returns grad_he_diag float32 with G's shape."""
+_NONFINITE_MSG = "BKCoreFunction backward: Incoming 'grad_output_features' contains NaN or Inf."
+_nonfinite = {}     # device -> [device flag (int32), pinned host copy, event of the last read-back or None]
+
+
+def _nonfinite_slot(device):
+    slot = _nonfinite.get(device)
+    if slot is None:
+        slot = [torch.zeros(1, dtype=torch.int32, device=device), torch.zeros(1, dtype=torch.int32).pin_memory(), None]
+        _nonfinite[device] = slot
+    return slot
+
+
+def poll_nonfinite_grad_warning(wait: bool = False) -> bool:
+    """With ``BKCoreFunction.WARN_NONFINITE_GRAD = "lazy"`` the backward kernel raises a device-side flag when the
+    incoming gradient holds a NaN or an infinity, and the flag travels to the host by an asynchronous copy.  This
+    function (also called at the start of every later backward) emits the reference's warning (bk_core.py:321-325)
+    for every read-back that has completed -- without waiting, unless ``wait`` -- and returns whether it warned."""
+    warned = False
+    for slot in _nonfinite.values():
+        ev = slot[2]
+        if ev is None:
+            continue
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            continue
+        slot[2] = None
+        if int(slot[1][0]) != 0:
+            slot[1][0] = 0
+            warnings.warn(_NONFINITE_MSG, RuntimeWarning)
+            logger.warning(_NONFINITE_MSG)
+            warned = True
+    return warned
+
+
+def bk_backward_reference(G, grad_features, grad_G, alpha: float, flag_nonfinite: bool = False):
+    """Launch the reference-mode backward kernel.  Returns grad_he_diag float32 with G's shape.
+    ``flag_nonfinite``: report a NaN / infinity in grad_features through poll_nonfinite_grad_warning()."""
     L = _lib.load()
     G = G.contiguous()
     out = torch.empty(G.shape, dtype=torch.float32, device=G.device)
@@ -212,8 +248,23 @@ def bk_backward_reference(G, grad_features, grad_G, alpha: float):
         gg = gg.contiguous()
     with _on_device(G.device):
         stream = torch.cuda.current_stream().cuda_stream
-        rc = L.bkcore_backward_ref(G.data_ptr(), gf.data_ptr() if gf is not None else None,
-                                   gg.data_ptr() if gg is not None else None, float(alpha), n, out.data_ptr(), stream)
+        if flag_nonfinite and gf is not None:
+            poll_nonfinite_grad_warning()
+            slot = _nonfinite_slot(G.device)
+            if slot[2] is not None:          # the previous read-back has not landed: let it, the flag is sticky
+                slot[2].synchronize()
+                poll_nonfinite_grad_warning()
+            rc = L.bkcore_backward_ref_flagged(G.data_ptr(), gf.data_ptr(), gg.data_ptr() if gg is not None else None,
+                                               float(alpha), n, out.data_ptr(), slot[0].data_ptr(), stream)
+            slot[1].copy_(slot[0], non_blocking=True)
+            slot[0].zero_()
+            ev = torch.cuda.Event()
+            ev.record()
+            slot[2] = ev
+        else:
+            rc = L.bkcore_backward_ref(G.data_ptr(), gf.data_ptr() if gf is not None else None,
+                                       gg.data_ptr() if gg is not None else None, float(alpha), n, out.data_ptr(),
+                                       stream)
     _lib.check(rc, "bkcore_backward_ref")
     return out
 
@@ -386,7 +437,10 @@ class BKCoreFunction(torch.autograd.Function):
     USE_PARALLEL_SCAN = True
     PHI_K_INDEX = "reference"
     GRAD_MODE = "reference"
-    WARN_NONFINITE_GRAD = False     # True: check the incoming gradient on the host and warn as bk_core.py:321-325 does
+    WARN_NONFINITE_GRAD = False     # True: check the incoming gradient on the host (one synchronisation per backward)
+                                    # and warn as bk_core.py:321-325 does; "lazy": the kernel raises a device-side
+                                    # flag, read back asynchronously -- the same warning, emitted by a later backward
+                                    # or by poll_nonfinite_grad_warning(), with no synchronisation
     SHARE_FEATURES_STORAGE = True   # features = the float32 view of G_ii (same numbers, bk_core.py:296-298) instead of
                                     # a second tensor: halves the bytes the forward writes.  An in-place modification
                                     # of either output then raises in autograd; False gives two separate tensors
@@ -423,11 +477,11 @@ class BKCoreFunction(torch.autograd.Function):
             return None, None, None, None, None, None
         # NaN / Inf in the incoming gradient count as 0 / +-max inside the kernels (torch.nan_to_num semantics,
         # bk_core.py:325); the reference also warns, which costs a host synchronisation, so that is opt-in
-        if BKCoreFunction.WARN_NONFINITE_GRAD and grad_output_features is not None \
+        lazy = BKCoreFunction.WARN_NONFINITE_GRAD == "lazy"
+        if BKCoreFunction.WARN_NONFINITE_GRAD and not lazy and grad_output_features is not None \
                 and not torch.isfinite(grad_output_features).all():
-            msg = "BKCoreFunction backward: Incoming 'grad_output_features' contains NaN or Inf."
-            warnings.warn(msg, RuntimeWarning)
-            logger.warning(msg)
+            warnings.warn(_NONFINITE_MSG, RuntimeWarning)
+            logger.warning(_NONFINITE_MSG)
         if ctx.bk_mode == "analytic":
             a, b, c, G = ctx.saved_tensors
             n = a.shape[-1]
@@ -445,7 +499,8 @@ class BKCoreFunction(torch.autograd.Function):
             gc_o = (gc * pc).reshape(sc) if ctx.needs_input_grad[2] else None
             return ga, gb_o, gc_o, None, None, None
         (G,) = ctx.saved_tensors
-        grad = bk_backward_reference(G, grad_output_features, grad_G_ii, BKCoreFunction.GRAD_BLEND)
+        grad = bk_backward_reference(G, grad_output_features, grad_G_ii, BKCoreFunction.GRAD_BLEND,
+                                     flag_nonfinite=lazy)
         return grad, None, None, None, None, None
 
 

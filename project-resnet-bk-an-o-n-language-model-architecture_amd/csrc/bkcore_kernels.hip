@@ -1083,9 +1083,10 @@ struct __attribute__((aligned(4))) V4a4 { bk_v4f v; };
 template <bool HAS_GF, bool HAS_GG>
 __global__ __launch_bounds__(256) void bk_backward_ref_kernel(const float2 *__restrict__ G, const float2 *__restrict__ gf,
                                                               const float2 *__restrict__ gG, float alpha, long n,
-                                                              float *__restrict__ out) {
+                                                              float *__restrict__ out, int *__restrict__ nonfinite) {
   const long stride = (long)gridDim.x * blockDim.x;
   const long nquads = n >> 2;
+  bool seen = false;  // a NaN or an infinity in grad_features (reported through *nonfinite when that is given)
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < nquads; p += stride) {
     const V4a8 *Gq = reinterpret_cast<const V4a8 *>(G + 4 * p);
     const bk_v4f G0 = __builtin_nontemporal_load(&Gq[0].v), G1 = __builtin_nontemporal_load(&Gq[1].v);
@@ -1094,6 +1095,10 @@ __global__ __launch_bounds__(256) void bk_backward_ref_kernel(const float2 *__re
       const V4a8 *q = reinterpret_cast<const V4a8 *>(gf + 4 * p);
       g0 = __builtin_nontemporal_load(&q[0].v);
       g1 = __builtin_nontemporal_load(&q[1].v);
+      if (nonfinite) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) seen |= !(fabsf(g0[i]) <= 3.4028234663852886e38f) || !(fabsf(g1[i]) <= 3.4028234663852886e38f);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         g0[i] = nan_to_num_default(g0[i]);
@@ -1115,10 +1120,14 @@ __global__ __launch_bounds__(256) void bk_backward_ref_kernel(const float2 *__re
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const long i = (n & ~3L) + threadIdx.x;
     float2 g = make_float2(0.f, 0.f);
-    if (HAS_GF) g = make_float2(nan_to_num_default(gf[i].x), nan_to_num_default(gf[i].y));
+    if (HAS_GF) {
+      seen |= !(fabsf(gf[i].x) <= 3.4028234663852886e38f) || !(fabsf(gf[i].y) <= 3.4028234663852886e38f);
+      g = make_float2(nan_to_num_default(gf[i].x), nan_to_num_default(gf[i].y));
+    }
     if (HAS_GG) { g.x += gG[i].x; g.y += gG[i].y; }
     out[i] = bwd_ref_one(G[i], g, alpha);
   }
+  if (nonfinite && seen) __hip_atomic_store(nonfinite, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- the caller's elementwise steps around the operator (resnet_bk.py:137-167, 216-217) ------------------------
@@ -1472,6 +1481,11 @@ int bkcore_internal_forward_save_rows(const float *a, int64_t lda, const float *
 
 int bkcore_backward_ref(const float *G, const float *grad_features, const float *grad_G, float alpha, int64_t n,
                         float *grad_a, void *stream) {
+  return bkcore_backward_ref_flagged(G, grad_features, grad_G, alpha, n, grad_a, nullptr, stream);
+}
+
+int bkcore_backward_ref_flagged(const float *G, const float *grad_features, const float *grad_G, float alpha, int64_t n,
+                                float *grad_a, int *nonfinite_flag, void *stream) {
   if (n < 0) return BKCORE_EINVAL;
   if (n == 0) return BKCORE_OK;
   if (!G || !grad_a) return BKCORE_EINVAL;
@@ -1483,13 +1497,17 @@ int bkcore_backward_ref(const float *G, const float *grad_features, const float 
   const dim3 grid((unsigned)blocks), block(256);
   const float2 *Gp = (const float2 *)G, *gf = (const float2 *)grad_features, *gg = (const float2 *)grad_G;
   if (gf && gg)
-    hipLaunchKernelGGL((bk_backward_ref_kernel<true, true>), grid, block, 0, s, Gp, gf, gg, alpha, (long)n, grad_a);
+    hipLaunchKernelGGL((bk_backward_ref_kernel<true, true>), grid, block, 0, s, Gp, gf, gg, alpha, (long)n, grad_a,
+                       nonfinite_flag);
   else if (gf)
-    hipLaunchKernelGGL((bk_backward_ref_kernel<true, false>), grid, block, 0, s, Gp, gf, gg, alpha, (long)n, grad_a);
+    hipLaunchKernelGGL((bk_backward_ref_kernel<true, false>), grid, block, 0, s, Gp, gf, gg, alpha, (long)n, grad_a,
+                       nonfinite_flag);
   else if (gg)
-    hipLaunchKernelGGL((bk_backward_ref_kernel<false, true>), grid, block, 0, s, Gp, gf, gg, alpha, (long)n, grad_a);
+    hipLaunchKernelGGL((bk_backward_ref_kernel<false, true>), grid, block, 0, s, Gp, gf, gg, alpha, (long)n, grad_a,
+                       nonfinite_flag);
   else
-    hipLaunchKernelGGL((bk_backward_ref_kernel<false, false>), grid, block, 0, s, Gp, gf, gg, alpha, (long)n, grad_a);
+    hipLaunchKernelGGL((bk_backward_ref_kernel<false, false>), grid, block, 0, s, Gp, gf, gg, alpha, (long)n, grad_a,
+                       nonfinite_flag);
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) {
     g_last_hip_error = (int)err;
@@ -1562,7 +1580,7 @@ int bkcore_layer_backward_ref(const float *G, const float *grad_features, const 
 int64_t bkcore_max_seq_len(void) { return (int64_t)MAX_N; }
 int bkcore_last_hip_error(void) { return g_last_hip_error; }
 void bkcore_internal_set_hip_error(int code) { g_last_hip_error = code; }
-int bkcore_abi_version(void) { return 10; }
+int bkcore_abi_version(void) { return 11; }
 
 const char *bkcore_error_string(int code) {
   switch (code) {

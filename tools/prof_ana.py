@@ -10,7 +10,7 @@ a = -2.0 + 0.5 * torch.randn(B, N, device="cuda", generator=g)
 b = 1.0 + 0.1 * torch.randn(B, N - 1, device="cuda", generator=g)
 c = 1.0 + 0.1 * torch.randn(B, N - 1, device="cuda", generator=g)
 gf = torch.randn(B, N, 2, device="cuda", generator=g)
-_, G = bkcore.bk_forward(a, b, c, 1j)
+_, G = bkcore.bk_forward(a, b, c, 1j, share_storage=True)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
     bkcore.bk_backward_analytic(a, b, c, 1j, gf, None, G=G)
 torch.cuda.synchronize()
