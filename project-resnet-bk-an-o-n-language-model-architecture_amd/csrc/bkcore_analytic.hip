@@ -19,11 +19,15 @@
 //     grad_a_m = Re[(lam_m/r_m + mu_m/s_m) D_m],   D_m = d a'_m / d a_m   (regularisation, bk_core.py:78-94)
 //     grad_k_m = -Re[w(r_m) lam_{m+1}/r_{m+1}]  -  Re[w(s_{m'+1}) mu_{m'}/s_{m'}] at kphi_{m'} = k_m
 //     grad_b = c grad_k,  grad_c = b grad_k
-// r, s and G_raw come from a forward launch inside bkcore_backward_analytic (nothing is kept from the caller's
-// forward).  Two kernels, one 256-thread workgroup per row, chunks of 256 x 8 elements; the scans run over affine
-// maps of R^2 (2x2 matrix + vector) with DPP inside a wave and LDS across waves:
-//   bk_adjoint_phi_kernel   : left -> right; P (prefix sum) and mu; writes P, the phi part of grad_a and of grad_k
-//   bk_adjoint_theta_kernel : right -> left; lam; adds the theta parts and writes grad_a, grad_b, grad_c
+// Two implementations in this file:
+//   bk_adjoint_sweeps (second half of the file): one pass over the row that needs only a, b, c, the forward's output G
+//     and the cotangent; the ratios are recomputed in the kernel; rows whose in-kernel checks fail are flagged.
+//   the three-pass path (first half): a forward launch that keeps r, s and G_raw, then bk_adjoint_phi_kernel
+//     (left -> right; P (prefix sum) and mu; writes P, the phi part of grad_a and of grad_k) and
+//     bk_adjoint_theta_kernel (right -> left; lam; adds the theta parts and writes grad_a, grad_b, grad_c), one
+//     256-thread workgroup per row, chunks of 256 x 8 elements, scans over affine maps of R^2 (2x2 matrix + vector)
+//     with DPP inside a wave and LDS across waves.  It makes no assumption about contraction and runs for the flagged
+//     rows, or for every row when the caller gives no state block.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
