@@ -107,6 +107,23 @@ int bkcore_backward_ref_flagged(const float *G, const float *grad_features, cons
                                 float *grad_a, int *nonfinite_flag, void *stream);
 
 /*
+ * The reference's other backward heuristics on the saved G, same arguments as bkcore_backward_ref plus `variant`:
+ *   BKCORE_BWD_REFERENCE   BKCoreFunction.backward, src/models/bk_core.py:303-385 (= bkcore_backward_ref)
+ *   BKCORE_BWD_BATCHED     compute_single_gradient of BatchedAnalyticBKCoreFunction / MemoryOptimizedBKCoreFunction,
+ *                          src/models/batched_gradient.py:12-54,65-130,174-217: the same blend with min |G^2| 1e-3, the
+ *                          cotangent not conjugated, a non-finite result -> 0, clamp +-1000; the cotangents are taken
+ *                          as they come (no nan_to_num)
+ *   BKCORE_BWD_SCAN_STABLE BKScanStableFunction.backward, src/kernels/bk_scan_stable.py:597: grad_a = -Re(g) |G|^2
+ *                          (alpha unused; grad_b, grad_c are zeros there, :605-609)
+ * The cotangent g is grad_features read as (Re, Im) pairs plus grad_G, either may be NULL.
+ */
+#define BKCORE_BWD_REFERENCE 0
+#define BKCORE_BWD_BATCHED 1
+#define BKCORE_BWD_SCAN_STABLE 2
+int bkcore_backward_variant(const float *G, const float *grad_features, const float *grad_G, float alpha, int64_t n,
+                            float *grad_a, int variant, void *stream);
+
+/*
  * Backward, analytic mode: the gradient of L with respect to he_diag, h0_super and h0_sub, where
  * dL = sum Re(conj(gbar) dG) and gbar = grad_features[...,0] + i grad_features[...,1] (+ grad_G).  It is the
  * derivative of what bkcore_forward computes -- regularisation, both soft clamps, the |G| <= 50 clip and the chosen

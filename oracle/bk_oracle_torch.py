@@ -161,6 +161,25 @@ def backward_reference(G, grad_features, grad_G, alpha: float):
     return gv.to(torch.float32)
 
 
+def backward_batched(G, grad_features, alpha: float):
+    """grad_he_diag of BatchedAnalyticBKCoreFunction / MemoryOptimizedBKCoreFunction: compute_single_gradient,
+    src/models/batched_gradient.py:12-54, on grad_G = complex(grad_features) (:116-119)."""
+    gg = torch.complex(grad_features[..., 0], grad_features[..., 1]).to(G.dtype)
+    g2 = G ** 2
+    mag = g2.abs()
+    den = torch.where(mag < 1e-3, g2 / (mag + 1e-9) * 1e-3, g2)      # :33-40
+    theo = -(gg * g2).real                                           # :43
+    h7 = -(gg / (den + 1e-6)).real                                   # :46
+    gv = (1.0 - alpha) * theo + alpha * h7                           # :49
+    gv = torch.where(torch.isfinite(gv), gv, torch.zeros_like(gv))   # :52
+    return torch.clamp(gv, -1000.0, 1000.0).to(torch.float32)        # :53
+
+
+def backward_scan_stable(G, grad_output):
+    """grad_a of BKScanStableFunction.backward, src/kernels/bk_scan_stable.py:597-598."""
+    return (-grad_output.to(G.dtype) * G * G.conj()).real.to(torch.float32)
+
+
 def analytic_grads(he_diag, h0_super, h0_sub, z, grad_features=None, grad_G=None,
                    phi_k_index: str = "reference"):
     """True gradients (d/da, d/db, d/dc) of L through the regularised, clamped forward,

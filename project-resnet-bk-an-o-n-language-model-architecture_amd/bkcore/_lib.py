@@ -14,11 +14,12 @@ FLAG_RAW = 1
 FLAG_PHI_EXACT = 2
 FLAG_SCAN_PATH = 4
 STATE_BYTES = 64
-ABI_VERSION = 11
+ABI_VERSION = 12
 EINVAL, ETOOLONG, ELAUNCH, EWORKSPACE, ETOOBIG = -1, -2, -3, -4, -5
+BWD_REFERENCE, BWD_BATCHED, BWD_SCAN_STABLE = 0, 1, 2
 NOALLOC_MAX_WORKSPACE = 8 << 20
 
-EXPORTS = ("bkcore_forward", "bkcore_forward_clamped", "bkcore_forward_noalloc", "bkcore_workspace_bytes", "bkcore_backward_ref", "bkcore_backward_ref_flagged", "bkcore_backward_analytic",
+EXPORTS = ("bkcore_forward", "bkcore_forward_clamped", "bkcore_forward_noalloc", "bkcore_workspace_bytes", "bkcore_backward_ref", "bkcore_backward_ref_flagged", "bkcore_backward_variant", "bkcore_backward_analytic",
            "bkcore_backward_analytic_workspace_bytes", "bkcore_backward_analytic_rowflag_offset", "bkcore_layer_prologue", "bkcore_layer_backward_ref",
            "bkcore_layer_epilogue", "bkcore_layer_epilogue_backward", "bkcore_layer_epilogue_backward_workspace_bytes", "bkcore_cumsum", "bkcore_woodbury_correct", "bkcore_woodbury_workspace_bytes",
            "bkcore_max_seq_len", "bkcore_last_hip_error",
@@ -52,6 +53,8 @@ def load():
     L.bkcore_backward_ref.restype = i32
     L.bkcore_backward_ref_flagged.argtypes = [vp, vp, vp, f32, i64, vp, vp, vp]
     L.bkcore_backward_ref_flagged.restype = i32
+    L.bkcore_backward_variant.argtypes = [vp, vp, vp, f32, i64, vp, i32, vp]
+    L.bkcore_backward_variant.restype = i32
     L.bkcore_backward_analytic.argtypes = [vp, i64, vp, i64, vp, i64, vp, f32, f32, i64, i64, vp, vp, vp, vp, vp, vp,
                                            vp, ctypes.c_size_t, vp, ctypes.c_uint, vp]
     L.bkcore_backward_analytic.restype = i32

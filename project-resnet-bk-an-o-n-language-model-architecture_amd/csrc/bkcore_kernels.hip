@@ -1075,12 +1075,36 @@ __device__ __forceinline__ float bwd_ref_one(float2 G, float2 g, float alpha) {
   return gv;
 }
 
+// The reference's other backward heuristics on the same saved G, as variants of the same elementwise pass:
+//   1: compute_single_gradient, src/models/batched_gradient.py:12-54 -- the blend with min |G^2| 1e-3, clamp +-1000 and
+//      the cotangent taken as it comes (not conjugated); a result that is not finite counts as 0
+//   2: BKScanStableFunction.backward, src/kernels/bk_scan_stable.py:597 -- grad_a = Re(-g G conj(G)) = -Re(g) |G|^2
+template <int VARIANT>
+__device__ __forceinline__ float bwd_one(float2 G, float2 g, float alpha) {
+  if (VARIANT == 0) return bwd_ref_one(G, g, alpha);
+  if (VARIANT == 2) return -g.x * fmaf(G.x, G.x, G.y * G.y);
+  const float2 g2 = cmul(G, G);
+  const float mag = sqrtf(fmaf(g2.x, g2.x, g2.y * g2.y));
+  float2 den = g2;
+  if (mag < 1e-3f) {
+    const float s = 1e-3f / (mag + 1e-9f);
+    den = make_float2(g2.x * s, g2.y * s);
+  }
+  den.x += 1e-6f;
+  const float theo = -fmaf(g.x, g2.x, -g.y * g2.y);              // -Re(g G^2)
+  const float dn = fmaf(den.x, den.x, den.y * den.y);
+  const float h7 = -fmaf(g.x, den.x, g.y * den.y) / dn;           // -Re(g / den)
+  float gv = fmaf(1.0f - alpha, theo, alpha * h7);
+  if (!(fabsf(gv) <= 3.4028234663852886e38f)) gv = 0.0f;
+  return fminf(fmaxf(gv, -1000.0f), 1000.0f);
+}
+
 // Four elements per thread per iteration: two 16-byte loads of G and of each cotangent (read once: nontemporal), one
 // 16-byte store.  The loads need only the 8-byte alignment of a complex64 / float pair.
 typedef float bk_v4f __attribute__((ext_vector_type(4)));
 struct __attribute__((aligned(8))) V4a8 { bk_v4f v; };
 struct __attribute__((aligned(4))) V4a4 { bk_v4f v; };
-template <bool HAS_GF, bool HAS_GG>
+template <bool HAS_GF, bool HAS_GG, int VARIANT = 0>
 __global__ __launch_bounds__(256) void bk_backward_ref_kernel(const float2 *__restrict__ G, const float2 *__restrict__ gf,
                                                               const float2 *__restrict__ gG, float alpha, long n,
                                                               float *__restrict__ out, int *__restrict__ nonfinite) {
@@ -1099,10 +1123,12 @@ __global__ __launch_bounds__(256) void bk_backward_ref_kernel(const float2 *__re
 #pragma unroll
         for (int i = 0; i < 4; ++i) seen |= !(fabsf(g0[i]) <= 3.4028234663852886e38f) || !(fabsf(g1[i]) <= 3.4028234663852886e38f);
       }
+      if (VARIANT == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        g0[i] = nan_to_num_default(g0[i]);
-        g1[i] = nan_to_num_default(g1[i]);
+        for (int i = 0; i < 4; ++i) {
+          g0[i] = nan_to_num_default(g0[i]);
+          g1[i] = nan_to_num_default(g1[i]);
+        }
       }
     }
     if (HAS_GG) {
@@ -1111,10 +1137,10 @@ __global__ __launch_bounds__(256) void bk_backward_ref_kernel(const float2 *__re
       g1 += __builtin_nontemporal_load(&q[1].v);
     }
     bk_v4f o;
-    o[0] = bwd_ref_one(make_float2(G0[0], G0[1]), make_float2(g0[0], g0[1]), alpha);
-    o[1] = bwd_ref_one(make_float2(G0[2], G0[3]), make_float2(g0[2], g0[3]), alpha);
-    o[2] = bwd_ref_one(make_float2(G1[0], G1[1]), make_float2(g1[0], g1[1]), alpha);
-    o[3] = bwd_ref_one(make_float2(G1[2], G1[3]), make_float2(g1[2], g1[3]), alpha);
+    o[0] = bwd_one<VARIANT>(make_float2(G0[0], G0[1]), make_float2(g0[0], g0[1]), alpha);
+    o[1] = bwd_one<VARIANT>(make_float2(G0[2], G0[3]), make_float2(g0[2], g0[3]), alpha);
+    o[2] = bwd_one<VARIANT>(make_float2(G1[0], G1[1]), make_float2(g1[0], g1[1]), alpha);
+    o[3] = bwd_one<VARIANT>(make_float2(G1[2], G1[3]), make_float2(g1[2], g1[3]), alpha);
     __builtin_nontemporal_store(o, &reinterpret_cast<V4a4 *>(out + 4 * p)->v);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -1122,10 +1148,10 @@ __global__ __launch_bounds__(256) void bk_backward_ref_kernel(const float2 *__re
     float2 g = make_float2(0.f, 0.f);
     if (HAS_GF) {
       seen |= !(fabsf(gf[i].x) <= 3.4028234663852886e38f) || !(fabsf(gf[i].y) <= 3.4028234663852886e38f);
-      g = make_float2(nan_to_num_default(gf[i].x), nan_to_num_default(gf[i].y));
+      g = VARIANT == 0 ? make_float2(nan_to_num_default(gf[i].x), nan_to_num_default(gf[i].y)) : gf[i];
     }
     if (HAS_GG) { g.x += gG[i].x; g.y += gG[i].y; }
-    out[i] = bwd_ref_one(G[i], g, alpha);
+    out[i] = bwd_one<VARIANT>(G[i], g, alpha);
   }
   if (nonfinite && seen) __hip_atomic_store(nonfinite, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1516,6 +1542,41 @@ int bkcore_backward_ref_flagged(const float *G, const float *grad_features, cons
   return BKCORE_OK;
 }
 
+int bkcore_backward_variant(const float *G, const float *grad_features, const float *grad_G, float alpha, int64_t n,
+                            float *grad_a, int variant, void *stream) {
+  if (variant == BKCORE_BWD_REFERENCE) return bkcore_backward_ref(G, grad_features, grad_G, alpha, n, grad_a, stream);
+  if (variant != BKCORE_BWD_BATCHED && variant != BKCORE_BWD_SCAN_STABLE) return BKCORE_EINVAL;
+  if (n < 0) return BKCORE_EINVAL;
+  if (n == 0) return BKCORE_OK;
+  if (!G || !grad_a) return BKCORE_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const long quads = (n + 3) / 4;
+  long blocks = (quads + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  const dim3 grid((unsigned)blocks), block(256);
+  const float2 *Gp = (const float2 *)G, *gf = (const float2 *)grad_features, *gg = (const float2 *)grad_G;
+#define BK_BV(GF, GG, V)                                                                                             \
+  hipLaunchKernelGGL((bk_backward_ref_kernel<GF, GG, V>), grid, block, 0, s, Gp, gf, gg, alpha, (long)n, grad_a,    \
+                     (int *)nullptr)
+#define BK_BV_ALL(V)                                                                                                 \
+  do {                                                                                                               \
+    if (gf && gg) BK_BV(true, true, V);                                                                              \
+    else if (gf) BK_BV(true, false, V);                                                                              \
+    else if (gg) BK_BV(false, true, V);                                                                              \
+    else BK_BV(false, false, V);                                                                                     \
+  } while (0)
+  if (variant == BKCORE_BWD_BATCHED) BK_BV_ALL(1);
+  else BK_BV_ALL(2);
+#undef BK_BV_ALL
+#undef BK_BV
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    g_last_hip_error = (int)err;
+    return BKCORE_ELAUNCH;
+  }
+  return BKCORE_OK;
+}
+
 int bkcore_layer_prologue(const float *v_pre, int64_t ldv, const float *h0_diag, float v_max, int64_t B, int64_t N,
                           void *he_diag, int out_dtype, void *stream) {
   if (B < 0 || N < 0 || ldv < 0 || !(v_max > 0.0f)) return BKCORE_EINVAL;
@@ -1580,7 +1641,7 @@ int bkcore_layer_backward_ref(const float *G, const float *grad_features, const 
 int64_t bkcore_max_seq_len(void) { return (int64_t)MAX_N; }
 int bkcore_last_hip_error(void) { return g_last_hip_error; }
 void bkcore_internal_set_hip_error(int code) { g_last_hip_error = code; }
-int bkcore_abi_version(void) { return 11; }
+int bkcore_abi_version(void) { return 12; }
 
 const char *bkcore_error_string(int code) {
   switch (code) {
