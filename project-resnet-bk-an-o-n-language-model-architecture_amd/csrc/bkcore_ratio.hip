@@ -417,7 +417,7 @@ __device__ __forceinline__ unsigned commit_ratio(const RowCfg &cfg, const float 
 // SAVE (MODE 0 only, for the analytic backward): also stores r_j and s_j, and writes G_raw (before the final
 // log-magnitude clamp and the clip; 0 outside 1e-18 <= |G_raw| <= 1e18) instead of G.
 template <typename TIn, bool PHI_EXACT, int MODE, bool SAVE = false>
-__global__ __launch_bounds__(RT, (MODE == 0 && !SAVE && !LONG) ? BK_RATIO_WAVES : 2) void bk_ratio_forward_kernel(
+__global__ __launch_bounds__(RT, (MODE == 0 && !SAVE && !LONG && sizeof(TIn) != 2) ? BK_RATIO_WAVES : 2) void bk_ratio_forward_kernel(
     const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
     const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, float2 *__restrict__ G_,
     float2 *__restrict__ F_, char *__restrict__ ws, int *state, unsigned flags, float fclamp, int S,
@@ -458,7 +458,9 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE && !LONG) ? BK_RATIO_WAVES 
   // SIMD (168 registers) when the loads are issued at the start of the chunk and the CU's other workgroups cover their
   // latency; the other variants hold the next chunk's inputs in registers during the current chunk's arithmetic
   // (2 waves per SIMD).
-  constexpr bool PREFETCH = !(MODE == 0 && !SAVE && BK_RATIO_WAVES >= 3) && !LONG && BK_RATIO_PREFETCH;
+  // 16-bit operands (the layer's bfloat16 diagonal) measured faster with two workgroups per CU and the prefetch:
+  // twice the load instructions per byte
+  constexpr bool PREFETCH = !(MODE == 0 && !SAVE && BK_RATIO_WAVES >= 3 && sizeof(TIn) != 2) && !LONG && BK_RATIO_PREFETCH;
   float av[RNJ], bv[RNJ], cv[RNJ];
   auto prefetch = [&](int ch) __attribute__((always_inline)) {
     // `full`: the chunk and its halos (and the one extra k) lie inside the row

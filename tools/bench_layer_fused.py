@@ -3,7 +3,11 @@ tensor-library ops around BKCoreFunction versus FusedBKLayerFunction (two librar
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "project-resnet-bk-an-o-n-language-model-architecture_amd"))
-import torch, bkcore
+import torch
+if os.environ.get('BKCORE_DEV_LIB'):
+    from bkcore import _lib
+    _lib.LIB_PATH = os.path.abspath(os.environ['BKCORE_DEV_LIB'])
+import bkcore
 
 B, N = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1024, 32768)
 dev = torch.device("cuda", 0)
