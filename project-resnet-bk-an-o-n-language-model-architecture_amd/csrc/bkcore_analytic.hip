@@ -476,6 +476,9 @@ __global__ __launch_bounds__(T) void bk_adjoint_theta_kernel(
 #ifndef BK_SWEEP_PREFETCH
 #define BK_SWEEP_PREFETCH 0   // 1: raw inputs of the next chunk held in registers during the current chunk's arithmetic
 #endif
+#ifndef BK_SWEEP_LDS_ABC
+#define BK_SWEEP_LDS_ABC 1   // raw a, b, c of the chunk kept in LDS for the output pass (0: read again from memory)
+#endif
 #ifndef BK_SWEEP_WG
 #define BK_SWEEP_WG 2   // workgroups per CU the register budget is set for
 #endif
@@ -493,8 +496,10 @@ struct SharedSweep {
   float2 al_s[SPAD];            // regularised diagonal of elements base - WH .. base + CHUNK + WH - 1
   float k_s[SPAD];              // k_{i-1} = b_{i-1} c_{i-1} for the same elements (0 outside the row)
   float2 q_s[QPAD];             // q of elements base .. base + CHUNK - 1
+#if BK_SWEEP_LDS_ABC
   float a_s[QPAD];              // he_diag of the same elements
   float2 bc_s[QPAD];            // (b_j, c_j) of the same elements
+#endif
   float2 sumtot[2][WAVES];
   float2 sumcarry[2];
   float2 wedge_t[2][WAVES];     // theta: lane 63 of each wave, om after its last own step
@@ -643,8 +648,12 @@ __device__ __forceinline__ void commit_chunk(const Raw &R, const float *__restri
       sh.k_s[q + q / EB] = R.bv[j] * R.cv[j];
       sh.al_s[q + q / EB] = reg_diag(R.av[j], z);
       const int e = q - WH;
+#if BK_SWEEP_LDS_ABC
       if (e >= 0 && e < CHUNK) sh.a_s[e + e / EB] = R.av[j];
       if (e >= 1 && e <= CHUNK) sh.bc_s[(e - 1) + (e - 1) / EB] = make_float2(R.bv[j], R.cv[j]);
+#else
+      (void)e;
+#endif
     }
   }
 #pragma unroll
@@ -942,15 +951,26 @@ __global__ __launch_bounds__(T, BK_SWEEP_WG) void bk_adjoint_sweeps(
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" : "+v"(to));
-    const float *a_l = sh.a_s + to * (EB + 1);
-    const float2 *bc_l = sh.bc_s + to * (EB + 1);
     float ao[EB];
     float2 bco[EB];
+#if BK_SWEEP_LDS_ABC
+    const float *a_l = sh.a_s + to * (EB + 1);
+    const float2 *bc_l = sh.bc_s + to * (EB + 1);
 #pragma unroll
     for (int e = 0; e < EB; ++e) {
       ao[e] = a_l[e];
       bco[e] = bc_l[e];
     }
+#else
+    {  // read again from memory (the chunk was staged from there a moment ago)
+      float bo[EB], co[EB];
+      load_block<EB>(a + base, to * EB, 0, N - base, 0.0f, ao);
+      load_block<EB>(b + base, to * EB, 0, N - 1 - base, 0.0f, bo);
+      load_block<EB>(c + base, to * EB, 0, N - 1 - base, 0.0f, co);
+#pragma unroll
+      for (int e = 0; e < EB; ++e) bco[e] = make_float2(bo[e], co[e]);
+    }
+#endif
     {
       // element 8: w(s_8) is what the phi warm-up ended on; element 9 (OFF = 1): one more step of mu through 8
       const float2 w8 = make_float2(inv8.x * wc8, inv8.y * wc8);
