@@ -1518,7 +1518,7 @@ int bkcore_backward_ref_flagged(const float *G, const float *grad_features, cons
   hipStream_t s = (hipStream_t)stream;
   const long quads = (n + 3) / 4;
   long blocks = (quads + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > (1L << 20)) blocks = 1L << 20;  // one quad per thread (measured faster than a grid-stride loop over fewer blocks)
   if (blocks < 1) blocks = 1;
   const dim3 grid((unsigned)blocks), block(256);
   const float2 *Gp = (const float2 *)G, *gf = (const float2 *)grad_features, *gg = (const float2 *)grad_G;
@@ -1552,7 +1552,7 @@ int bkcore_backward_variant(const float *G, const float *grad_features, const fl
   hipStream_t s = (hipStream_t)stream;
   const long quads = (n + 3) / 4;
   long blocks = (quads + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > (1L << 20)) blocks = 1L << 20;  // one quad per thread (measured faster than a grid-stride loop over fewer blocks)
   const dim3 grid((unsigned)blocks), block(256);
   const float2 *Gp = (const float2 *)G, *gf = (const float2 *)grad_features, *gg = (const float2 *)grad_G;
 #define BK_BV(GF, GG, V)                                                                                             \
