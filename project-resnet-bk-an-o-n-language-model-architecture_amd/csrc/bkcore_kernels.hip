@@ -1218,31 +1218,57 @@ __global__ __launch_bounds__(256) void bk_layer_backward_ref_kernel(const float2
                                                                     float fclamp, const float *__restrict__ v_pre,
                                                                     float v_max, float inv_v_max, int round_bf16, long n,
                                                                     float *__restrict__ out) {
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float2 Gv = G[i];
+  // one element: clamp mask, the operator's reference-mode gradient, its rounding, tanh and nan_to_num masks
+  auto one = [&](float2 Gv, float2 gfv, float2 gGv, float v) -> float {
     float2 g = make_float2(0.f, 0.f);
     if (HAS_GF) {
-      g = gf[i];
+      g = gfv;
       if (!(fabsf(Gv.x) <= fclamp)) g.x = 0.0f;   // clamp passes the gradient on [-fclamp, fclamp] only
       if (!(fabsf(Gv.y) <= fclamp)) g.y = 0.0f;
       g.x = nan_to_num_default(g.x);
       g.y = nan_to_num_default(g.y);
     }
     if (HAS_GG) {
-      const float2 q = gG[i];
-      g.x += q.x;
-      g.y += q.y;
+      g.x += gGv.x;
+      g.y += gGv.y;
     }
     float ga = bwd_ref_one(Gv, g, alpha);
     if (round_bf16) ga = bf16_round(ga);
-    const float v = v_pre[i];
     float gv = 0.0f;
     if (fabsf(v) <= 3.4028234663852886e38f) {       // nan_to_num passes the gradient of finite entries only
       const float th = tanhf(v * inv_v_max);
       gv = ((ga * v_max) * (1.0f - th * th)) * inv_v_max;
     }
-    __builtin_nontemporal_store(gv, &out[i]);
+    return gv;
+  };
+  // four elements per thread per iteration, 16-byte nontemporal accesses (everything is read once)
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long nquads = n >> 2;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < nquads; p += stride) {
+    const V4a8 *Gq = reinterpret_cast<const V4a8 *>(G + 4 * p);
+    const bk_v4f G0 = __builtin_nontemporal_load(&Gq[0].v), G1 = __builtin_nontemporal_load(&Gq[1].v);
+    bk_v4f g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, h0 = g0, h1 = g0;
+    if (HAS_GF) {
+      const V4a8 *q = reinterpret_cast<const V4a8 *>(gf + 4 * p);
+      g0 = __builtin_nontemporal_load(&q[0].v);
+      g1 = __builtin_nontemporal_load(&q[1].v);
+    }
+    if (HAS_GG) {
+      const V4a8 *q = reinterpret_cast<const V4a8 *>(gG + 4 * p);
+      h0 = __builtin_nontemporal_load(&q[0].v);
+      h1 = __builtin_nontemporal_load(&q[1].v);
+    }
+    const bk_v4f vq = __builtin_nontemporal_load(&reinterpret_cast<const V4a4 *>(v_pre + 4 * p)->v);
+    bk_v4f o;
+    o[0] = one(make_float2(G0[0], G0[1]), make_float2(g0[0], g0[1]), make_float2(h0[0], h0[1]), vq[0]);
+    o[1] = one(make_float2(G0[2], G0[3]), make_float2(g0[2], g0[3]), make_float2(h0[2], h0[3]), vq[1]);
+    o[2] = one(make_float2(G1[0], G1[1]), make_float2(g1[0], g1[1]), make_float2(h1[0], h1[1]), vq[2]);
+    o[3] = one(make_float2(G1[2], G1[3]), make_float2(g1[2], g1[3]), make_float2(h1[2], h1[3]), vq[3]);
+    __builtin_nontemporal_store(o, &reinterpret_cast<V4a4 *>(out + 4 * p)->v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = (n & ~3L) + threadIdx.x;
+    out[i] = one(G[i], HAS_GF ? gf[i] : make_float2(0.f, 0.f), HAS_GG ? gG[i] : make_float2(0.f, 0.f), v_pre[i]);
   }
 }
 
@@ -1617,8 +1643,8 @@ int bkcore_layer_backward_ref(const float *G, const float *grad_features, const 
   if (!G || !v_pre || !grad_v) return BKCORE_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const float fc = feature_clamp > 0.0f ? feature_clamp : __builtin_huge_valf();
-  long blocks = (n + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
+  long blocks = ((n + 3) / 4 + 255) / 256;     // four elements per thread, one pass
+  if (blocks > (1L << 20)) blocks = 1L << 20;
   const dim3 grid((unsigned)blocks), block(256);
   const float inv = 1.0f / v_max;
   const float2 *Gp = (const float2 *)G, *gf = (const float2 *)grad_features, *gg = (const float2 *)grad_G;
