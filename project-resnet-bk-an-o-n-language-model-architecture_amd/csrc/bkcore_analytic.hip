@@ -501,7 +501,8 @@ struct SharedSweep {
   float2 bc_s[QPAD];            // (b_j, c_j) of the same elements
 #endif
   float2 sumtot[2][WAVES];
-  float2 sumcarry[2];
+  double2 sumcarry[2];          // sum of q over everything before the chunk: the one sum that runs over the whole row
+                                // (float32 would lose 1e-7 sqrt(N) of a typical term: 1e-4 at N = 2^20)
   float2 wedge_t[2][WAVES];     // theta: lane 63 of each wave, om after its last own step
   float2 wedge_p[2][WAVES];     // phi: lane 63 of each wave, its warm-up estimate
   float2 edge_t[2], edge_p[2];  // the same of lane T - 3, the left neighbour of the next chunk's first lane
@@ -700,7 +701,7 @@ __global__ __launch_bounds__(T, BK_SWEEP_WG) void bk_adjoint_sweeps(
   const int nch = N <= CHUNK ? 1 : 1 + (int)((N - CHUNK + STRIDE - 1) / STRIDE);
   bool bad = false;
   if (t == 0) {
-    sh.sumcarry[0] = make_float2(0.f, 0.f);
+    sh.sumcarry[0] = make_double2(0.0, 0.0);
     sh.xc_p[1][0] = make_float4(0.f, 0.f, 0.f, 0.f);
     sh.xc_p[1][1] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -839,13 +840,18 @@ __global__ __launch_bounds__(T, BK_SWEEP_WG) void bk_adjoint_sweeps(
     __syncthreads();
     BK_SSTAMP(3);
     {
-      float2 x = sh.sumcarry[buf];
+      const double2 carry = sh.sumcarry[buf];
+      float2 x = make_float2(0.f, 0.f);  // sum over the chunk's lanes before this one
 #pragma unroll
       for (int w = 0; w < WAVES; ++w) {
         if (w == wave) run = cadd(run, x);
         x = cadd(x, sh.sumtot[buf][w]);
       }
-      if (tl == T - 1 - HALO_LANES) sh.sumcarry[buf ^ 1] = cadd(run, pre[EB]);  // sum up to the next chunk's start
+      if (tl == T - 1 - HALO_LANES) {  // sum up to the next chunk's start
+        const float2 upto = cadd(run, pre[EB]);
+        sh.sumcarry[buf ^ 1] = make_double2(carry.x + (double)upto.x, carry.y + (double)upto.y);
+      }
+      run = make_float2((float)(carry.x + (double)run.x), (float)(carry.y + (double)run.y));
       // the left neighbour's last own step (theta) / warm-up (phi) and this lane's warm-up (theta) / first own step
       // (phi) are two evaluations of the same om
       if (lane == 0) {
