@@ -369,9 +369,34 @@ def secondary_measurements(torch, bkcore, device, B, N, ad, b, c, z, gfeat, time
             ts.append(time.perf_counter() - t0)
         mean_ms = sum(ts) / len(ts) * 1e3
         mag = Gp.abs()
+        # the same with the opt-in adaptive path (after such a batch the fast path's arithmetic is skipped), and the
+        # same distribution at the headline size
+        def _timed_calls(n):
+            for _ in range(20):
+                bkcore.BKCoreFunction.apply(ap_, bp_, cp_, zp, False)
+            torch.cuda.synchronize()
+            tt = []
+            for _ in range(n):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                bkcore.BKCoreFunction.apply(ap_, bp_, cp_, zp, False)
+                torch.cuda.synchronize()
+                tt.append(time.perf_counter() - t0)
+            return sum(tt) / len(tt) * 1e3
+        bkcore.BKCoreFunction.ADAPTIVE_PATH = True
+        try:
+            adaptive_ms = _timed_calls(100)
+            ah, bh, ch_ = (torch.randn(B, n_, generator=gp, device=device) for n_ in (N, N - 1, N - 1))
+            t_ill_adaptive = timed(lambda: bkcore.bk_forward(ah, bh, ch_, zp, share_storage=share), 20)
+        finally:
+            bkcore.BKCoreFunction.ADAPTIVE_PATH = False
+        t_ill = timed(lambda: bkcore.bk_forward(ah, bh, ch_, zp, share_storage=share), 20)
+        del ah, bh, ch_
         out["published_protocol"] = {
             "shape": "B=16 N=4096 randn a,b,c z=0.1+0.1j forward only, host timer + synchronize per call",
             "mean_ms": mean_ms, "min_ms": min(ts) * 1e3, "diag_elems_per_sec": 16 * 4096 / (mean_ms * 1e-3),
+            "mean_ms_adaptive_path": adaptive_ms,
+            "same_distribution_B%d_N%d_fwd_ms" % (B, N): {"default": t_ill * 1e3, "adaptive_path": t_ill_adaptive * 1e3},
             "reference_rtx3080_triton_ms": 2.73, "reference_rtx3080_torch_ms": 544.22,
             "finite_frac": float(torch.isfinite(torch.view_as_real(Gp)).all(-1).float().mean()),
             "clip_frac": float((mag > 49.99).float().mean()), "zero_frac": float((mag == 0).float().mean())}

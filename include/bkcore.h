@@ -38,6 +38,13 @@ extern "C" {
 
 #define BKCORE_FLAG_SCAN_PATH 4u  /* diagnostics: take the scan-based first launch instead of the ratio-form one
                                      (same results within the tolerance; see bkcore_forward) */
+#define BKCORE_FLAG_ADAPTIVE 8u   /* opt-in: when the previous call on this state block had to recompute more than half of
+                                   * its rows with the scan kernel (inputs on which the ratio maps do not contract, e.g.
+                                   * the randn distribution of scripts/benchmark_bk_triton.py:66-70), the next calls skip
+                                   * the ratio-form arithmetic (the inputs are still read once for the NaN verdicts) and
+                                   * go to the scan kernel for every row; every 16th such call tries the fast path again.
+                                   * Which kernel computes a well-conditioned row then depends on the calls before it: the
+                                   * two kernels agree to the operator's tolerance, not bit for bit. */
 
 /* error codes */
 #define BKCORE_OK 0

@@ -162,7 +162,8 @@ def bk_forward(a, b, c, z, raw: bool = False, phi_exact: bool = False, want_feat
         zkeep, pz, zre, zim = _prep_z(z, dev)
         state = _state_block(dev, stream)
         flags = (_lib.FLAG_RAW if raw else 0) | (_lib.FLAG_PHI_EXACT if phi_exact else 0) \
-            | (_lib.FLAG_SCAN_PATH if _DEBUG["scan_path"] else 0)
+            | (_lib.FLAG_SCAN_PATH if _DEBUG["scan_path"] else 0) \
+            | (_lib.FLAG_ADAPTIVE if BKCoreFunction.ADAPTIVE_PATH else 0)
         ws, ws_bytes = _workspace(L, dev, stream, B, N)
         if _DEBUG["keep_ws"]:       # diagnostics read the workspace after the call: give this call its own
             ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
@@ -441,6 +442,11 @@ class BKCoreFunction(torch.autograd.Function):
                                     # and warn as bk_core.py:321-325 does; "lazy": the kernel raises a device-side
                                     # flag, read back asynchronously -- the same warning, emitted by a later backward
                                     # or by poll_nonfinite_grad_warning(), with no synchronisation
+    ADAPTIVE_PATH = False           # True: a call whose predecessor (same device and stream) had to recompute more than
+                                    # half of its rows with the scan kernel skips the fast path's arithmetic; every
+                                    # 16th such call tries it again.  Which kernel computes a well-conditioned row then
+                                    # depends on the calls before it (same numbers to the operator's tolerance, not
+                                    # bit for bit), hence off by default
     SHARE_FEATURES_STORAGE = True   # features = the float32 view of G_ii (same numbers, bk_core.py:296-298) instead of
                                     # a second tensor: halves the bytes the forward writes.  An in-place modification
                                     # of either output then raises in autograd; False gives two separate tensors

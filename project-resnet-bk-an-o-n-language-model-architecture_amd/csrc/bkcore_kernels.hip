@@ -555,11 +555,22 @@ __device__ __forceinline__ void sweepB_range(const TIn *__restrict__ a, const TI
 // a flag is up, every workgroup of that last launch takes a ticket in state[4] once it has read the flags and done its
 // work, and the last ticket puts the block back to zero for the next call on the stream.  All of it lives on the
 // device, so a captured forward replays correctly in a HIP graph.
-__device__ __forceinline__ void state_release(int *state) {
+__device__ __forceinline__ void state_release(int *state, bool redone = false, bool adaptive = false) {
   __syncthreads();
   if (threadIdx.x == 0) {
+    if (adaptive && redone) __hip_atomic_fetch_add(&state[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int ticket = __hip_atomic_fetch_add(&state[4], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (ticket == (int)gridDim.x - 1) {
+      if (adaptive) {
+        // state[6] rows recomputed by this launch; state[7] "most rows were recomputed": the next calls with
+        // BKCORE_FLAG_ADAPTIVE skip the fast path's arithmetic, except when state[8] (calls since) wraps to 0
+        const int cnt = __hip_atomic_load(&state[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int since = __hip_atomic_load(&state[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool most = 2 * (long)cnt > (long)gridDim.x;
+        __hip_atomic_store(&state[7], most ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&state[8], most ? ((since + 1) & 15) : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&state[6], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       __hip_atomic_store(&state[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&state[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&state[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -593,7 +604,7 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
     fix_bc = (sa != 0 && sb != 0) && !(flags & BKCORE_FLAG_RAW);
     const bool redo_row = sc != 0 && rowflag[row] != 0;
     if (!fix_bc && !redo_row) {
-      state_release(state);
+      state_release(state, false, (flags & BKCORE_FLAG_ADAPTIVE) != 0);
       return;
     }
   }
@@ -655,7 +666,7 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
     if (seen & 1u) __hip_atomic_store(&state[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (seen & 2u) __hip_atomic_store(&state[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (second) state_release(state);
+  if (second) state_release(state, true, (flags & BKCORE_FLAG_ADAPTIVE) != 0);
 }
 
 // ---- long rows, few of them: several workgroups per row --------------------------------------------------------
@@ -1667,7 +1678,7 @@ int bkcore_layer_backward_ref(const float *G, const float *grad_features, const 
 int64_t bkcore_max_seq_len(void) { return (int64_t)MAX_N; }
 int bkcore_last_hip_error(void) { return g_last_hip_error; }
 void bkcore_internal_set_hip_error(int code) { g_last_hip_error = code; }
-int bkcore_abi_version(void) { return 12; }
+int bkcore_abi_version(void) { return 13; }
 
 const char *bkcore_error_string(int code) {
   switch (code) {

@@ -453,6 +453,12 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE && !LONG && sizeof(TIn) != 
   if (t == 0) {
     sh.carry[0] = MODE == 2 ? get_prod(info, 12, 20, 14) : prod_one();
   }
+  // BKCORE_FLAG_ADAPTIVE: the previous call recomputed most of its rows (state[7]) and this is not one of the calls
+  // that try again (state[8] == 0): only read and stage the inputs (that is what finds the NaN verdicts the second
+  // launch needs), skip the arithmetic, and leave every row to the scan kernel
+  const bool skip_arith = MODE == 0 && !SAVE && (flags & BKCORE_FLAG_ADAPTIVE) && state &&
+                          __hip_atomic_load(&state[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+                          __hip_atomic_load(&state[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 
   // Raw inputs of the chunk about to be processed.  One workgroup per row without the saving stores fits 3 waves per
   // SIMD (168 registers) when the loads are issued at the start of the chunk and the CU's other workgroups cover their
@@ -479,6 +485,10 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE && !LONG && sizeof(TIn) != 
     __syncthreads();
     BK_STAMP(3);
     if (PREFETCH && ch > ch0) prefetch(ch - 1);  // in flight during this chunk's arithmetic
+    if (skip_arith) {  // uniform over the grid
+      bad = true;
+      return;
+    }
 
     const int q0 = seg * E + RH;      // staged slot of the lane's first element (a multiple of 16)
     const float2 *al_l = sh.u.in.al_s + rpad16(q0);
