@@ -485,10 +485,6 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE && !LONG && sizeof(TIn) != 
     __syncthreads();
     BK_STAMP(3);
     if (PREFETCH && ch > ch0) prefetch(ch - 1);  // in flight during this chunk's arithmetic
-    if (skip_arith) {  // uniform over the grid
-      bad = true;
-      return;
-    }
 
     const int q0 = seg * E + RH;      // staged slot of the lane's first element (a multiple of 16)
     const float2 *al_l = sh.u.in.al_s + rpad16(q0);
@@ -755,10 +751,21 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE && !LONG && sizeof(TIn) != 
   for (int i = (int)((blockIdx.x * 2654435761u) >> 28); i > 0; --i) __builtin_amdgcn_s_sleep(BK_RATIO_STAGGER);
 #endif
   // chunk kinds: those within reach of a halo of the end of the row (the last one or two), then the others
-  if (PREFETCH) prefetch(ch1 - 1);
-  int ch = ch1 - 1;
-  for (; ch >= ch0 && (long)(ch + 1) * RCHUNK + RH + 1 > N; --ch) one(BoolC<true>{}, ch);
-  for (; ch >= ch0; --ch) one(BoolC<false>{}, ch);
+  if (skip_arith) {  // uniform over the grid: stage every chunk for its NaN verdicts, nothing else
+#pragma unroll 1
+    for (int ch = ch1 - 1; ch >= ch0; --ch) {
+      prefetch(ch);
+      __syncthreads();
+      seen |= commit_ratio(cfg, av, bv, cv, sh);
+      __syncthreads();
+    }
+    bad = true;
+  } else {
+    if (PREFETCH) prefetch(ch1 - 1);
+    int ch = ch1 - 1;
+    for (; ch >= ch0 && (long)(ch + 1) * RCHUNK + RH + 1 > N; --ch) one(BoolC<true>{}, ch);
+    for (; ch >= ch0; --ch) one(BoolC<false>{}, ch);
+  }
 #if BK_RATIO_STAMPS
   if (threadIdx.x == 0)
     reinterpret_cast<unsigned long long *>(ws + rowflag_bytes(B))[(row * nch) * 16 + 15] = wall_clock64();
