@@ -490,6 +490,7 @@ static_assert(SN % EB == 0 && WH % EB == 0, "padded slot arithmetic");
 // offset of slot d (may be negative) from a slot whose index is a multiple of EB, in the layout q -> q + q / EB
 __device__ __forceinline__ constexpr int soff(int d) { return d + (d >= 0 ? d / EB : -((EB - 1 - d) / EB)); }
 
+constexpr int SWEEP_MAX_SEGMENTS = 64;              // workgroups per row at most (few long rows)
 constexpr int HALO_LANES = 2;                       // lanes at the end of a chunk that the next chunk computes again
 constexpr int STRIDE = CHUNK - HALO_LANES * EB;     // elements a chunk advances by
 struct SharedSweep {
@@ -686,9 +687,17 @@ __global__ __launch_bounds__(T, BK_SWEEP_WG) void bk_adjoint_sweeps(
     const float *__restrict__ a_, long lda, const float *__restrict__ b_, long ldb, const float *__restrict__ c_,
     long ldc, const float *__restrict__ z_dev, float z_re, float z_im, long N, const float *__restrict__ G_,
     const float *__restrict__ gf_, const float *__restrict__ gG_, float *__restrict__ ga_, float *__restrict__ gb_,
-    float *__restrict__ gc_, int *__restrict__ rowbad, int *state, unsigned long long *dbg) {
+    float *__restrict__ gc_, int *__restrict__ rowbad, int *state, unsigned long long *dbg, int S, long seg_len,
+    const double2 *__restrict__ segsum) {
   __shared__ SharedSweep sh;
-  const long row = blockIdx.x;
+  // Few long rows: a row is cut into S segments of seg_len elements, one workgroup each.  A
+  // segment after the first starts two lanes early: mu enters those lanes as 0, which reaches only them (their results
+  // belong to the segment before), exactly as lam does at the end of every chunk; the sum of q over everything before
+  // the segment comes from bk_adjoint_segsum.
+  const long row = S == 1 ? (long)blockIdx.x : (long)(blockIdx.x / S);
+  const int sg = S == 1 ? 0 : (int)(blockIdx.x % S);
+  const long out_lo = (long)sg * seg_len, out_hi = sg == S - 1 ? N : min(N, out_lo + seg_len);
+  const long start = out_lo > 0 ? out_lo - HALO_LANES * EB : 0;
   const float *a = a_ + row * lda;
   const float *b = N >= 2 ? b_ + row * ldb : a, *c = N >= 2 ? c_ + row * ldc : a;
   const float *G = G_ + row * N * 2;
@@ -698,18 +707,28 @@ __global__ __launch_bounds__(T, BK_SWEEP_WG) void bk_adjoint_sweeps(
   float *gc = gc_ ? gc_ + row * (N - 1) : nullptr;
   const float2 z = z_dev ? make_float2(z_dev[0], z_dev[1]) : make_float2(z_re, z_im);
   const int t = threadIdx.x;
-  const int nch = N <= CHUNK ? 1 : 1 + (int)((N - CHUNK + STRIDE - 1) / STRIDE);
+  const int nch = N <= CHUNK ? 1 : 1 + (int)((N - CHUNK + STRIDE - 1) / STRIDE);  // (index of the debug stamps)
+  (void)nch;
   bool bad = false;
   if (t == 0) {
-    sh.sumcarry[0] = make_double2(0.0, 0.0);
+    double2 before = make_double2(0.0, 0.0);
+    for (int q = 0; q < sg; ++q) {
+      const double2 v = segsum[row * S + q];
+      before.x += v.x;
+      before.y += v.y;
+    }
+    sh.sumcarry[0] = before;
     sh.xc_p[1][0] = make_float4(0.f, 0.f, 0.f, 0.f);
     sh.xc_p[1][1] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   Raw R;
-  if (BK_SWEEP_PREFETCH) issue_chunk(a, b, c, G, gf, 0, N, R, t);
-  for (int cc = 0; cc < nch; ++cc) {
+  if (BK_SWEEP_PREFETCH) issue_chunk(a, b, c, G, gf, start, N, R, t);
+  bool more = true;
+  for (int cc = 0; more; ++cc) {
     const int buf = cc & 1;
-    const long base = (long)cc * STRIDE;
+    const long base = start + (long)cc * STRIDE;
+    const bool reaches_end = base + CHUNK >= N;                   // the chunk holds the end of the row
+    more = !reaches_end && base + STRIDE < out_hi;
     const bool tail = base + CHUNK + WH >= N - 1;  // the end of the row lies in what this chunk stages
     BK_SSTAMP(0);
     // (the thread index goes through an opaque copy at each stage: offsets derived from it are then recomputed where
@@ -864,7 +883,7 @@ __global__ __launch_bounds__(T, BK_SWEEP_WG) void bk_adjoint_sweeps(
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e <= EB; ++e) pre[e] = cadd(pre[e], run);  // pre[e] = P_{first + e - 1}
-    if (BK_SWEEP_PREFETCH && cc + 1 < nch) issue_chunk(a, b, c, G, gf, base + STRIDE, N, R, tl);
+    if (BK_SWEEP_PREFETCH && more) issue_chunk(a, b, c, G, gf, base + STRIDE, N, R, tl);
     __builtin_amdgcn_sched_barrier(0);
     // the lane's maps applied to 0 and the product of their linear parts, for both adjoints:
     //   mu  (left -> right): c0 = P_{j-1},  off-diagonal product kphi_{j-1} = slot e - OFF
@@ -1001,7 +1020,8 @@ __global__ __launch_bounds__(T, BK_SWEEP_WG) void bk_adjoint_sweeps(
       gcv[e] = finite_or_zero(bco[e].x * gk[e]);
     }
     BK_SSTAMP(6);
-    if (cc == nch - 1 || to < T - HALO_LANES) {
+    const long first_o = base + (long)to * EB;
+    if ((reaches_end || to < T - HALO_LANES) && first_o >= out_lo && first_o < out_hi) {
       store_block<EB>(ga + base, to * EB, 0, N - base, gav);
       if (gb) {
         store_block<EB>(gb + base, to * EB, 0, N - 1 - base, gbv);
@@ -1012,8 +1032,54 @@ __global__ __launch_bounds__(T, BK_SWEEP_WG) void bk_adjoint_sweeps(
   }
   const int any_bad = __syncthreads_or(bad ? 1 : 0);
   if (threadIdx.x == 0) {
-    rowbad[row] = any_bad;
+    if (S == 1) rowbad[row] = any_bad;                            // (with segments bk_adjoint_segsum zeroed it)
+    else if (any_bad) __hip_atomic_store(&rowbad[row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (any_bad) __hip_atomic_store(&state[5], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Sum of q over each segment's own stretch [start_s, start_{s+1}) of the row (start_s = where the segment's first chunk
+// begins), for the prefix sums of bk_adjoint_sweeps run with several workgroups per row.  Also clears the row's flag.
+__global__ __launch_bounds__(T) void bk_adjoint_segsum(const float *__restrict__ G_, const float *__restrict__ gf_,
+                                                       const float *__restrict__ gG_, long N, int S, long seg_len,
+                                                       double2 *__restrict__ segsum, int *__restrict__ rowbad) {
+  __shared__ double2 part[T];
+  const long row = blockIdx.x / S;
+  const int sg = (int)(blockIdx.x % S);
+  const float *G = G_ + row * N * 2;
+  const float *gf = gf_ ? gf_ + row * N * 2 : nullptr, *gG = gG_ ? gG_ + row * N * 2 : nullptr;
+  const long lo = sg == 0 ? 0 : (long)sg * seg_len - HALO_LANES * EB;
+  const long hi = sg == S - 1 ? N : min(N, (long)(sg + 1) * seg_len - HALO_LANES * EB);
+  float2 acc = make_float2(0.f, 0.f);
+  double2 tot = make_double2(0.0, 0.0);
+  int n = 0;
+  for (long i = lo + threadIdx.x; i < hi; i += T) {
+    float2 g = gf ? ld2(gf + 2 * i) : make_float2(0.f, 0.f);
+    if (gG) g = cadd(g, ld2(gG + 2 * i));
+    const float gx = fabsf(g.x) <= 3.0e38f ? g.x : 0.0f;
+    const float gy = fabsf(g.y) <= 3.0e38f ? g.y : 0.0f;
+    acc = cadd(acc, cot_q_saved(ld2(G + 2 * i), make_float2(gx, gy)));
+    if (++n == 64) {  // short float32 runs, collected in double
+      tot.x += acc.x;
+      tot.y += acc.y;
+      acc = make_float2(0.f, 0.f);
+      n = 0;
+    }
+  }
+  tot.x += acc.x;
+  tot.y += acc.y;
+  part[threadIdx.x] = tot;
+  __syncthreads();
+  for (int w = T / 2; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      part[threadIdx.x].x += part[threadIdx.x + w].x;
+      part[threadIdx.x].y += part[threadIdx.x + w].y;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    segsum[row * S + sg] = part[0];
+    if (sg == 0) rowbad[row] = 0;
   }
 }
 
@@ -1025,12 +1091,29 @@ __global__ void bk_adjoint_finish(int *state) {
 
 extern "C" {
 
+// Segments per row for bk_adjoint_sweeps: rows are cut only when there are too few of them to occupy the chip
+static void sweep_plan(int64_t B, int64_t N, int &S, long &seg_len) {
+  S = 1;
+  seg_len = 0;
+  const long chunks = (long)((N + STRIDE - 1) / STRIDE);
+  if (B > 128 || chunks < 16) return;
+  long want = (1024 + B - 1) / B;
+  if (want > chunks / 8) want = chunks / 8;     // at least eight chunks per segment
+  if (want > SWEEP_MAX_SEGMENTS) want = SWEEP_MAX_SEGMENTS;
+  if (want < 2) return;
+  // m chunks per segment: the first one of a later segment starts two lanes early, so m chunks cover m * STRIDE
+  // minus those two lanes
+  seg_len = (chunks + want - 1) / want * STRIDE - HALO_LANES * EB;
+  S = (int)((N + seg_len - 1) / seg_len);
+  if (S < 2) { S = 1; seg_len = 0; }
+}
+
 size_t bkcore_backward_analytic_workspace_bytes(int64_t B, int64_t N) {
   if (B <= 0 || N <= 0) return 0;
   // forward scratch + four complex64 planes (G_raw, r, s, P of the three-pass path; the P plane also takes G when the
   // caller did not keep it) + one flag per row
   return ((bkcore_workspace_bytes(B, N) + 255) & ~(size_t)255) + 4 * (size_t)B * (size_t)N * 2 * sizeof(float) +
-         (((size_t)B * sizeof(int) + 255) & ~(size_t)255);
+         (((size_t)B * sizeof(int) + 255) & ~(size_t)255) + (size_t)B * SWEEP_MAX_SEGMENTS * sizeof(double2);
 }
 
 size_t bkcore_backward_analytic_rowflag_offset(int64_t B, int64_t N) {
@@ -1060,6 +1143,7 @@ int bkcore_backward_analytic(const float *a, int64_t lda, const float *b, int64_
   float *ss = (float *)(ws + fwd_ws + 2 * plane);
   float *Pp = (float *)(ws + fwd_ws + 3 * plane);
   int *rowbad = (int *)(ws + fwd_ws + 4 * plane);
+  double2 *segsum = (double2 *)(ws + fwd_ws + 4 * plane + (((size_t)B * sizeof(int) + 255) & ~(size_t)255));
   hipStream_t s = (hipStream_t)stream;
   float *gk = N > 1 ? grad_b : nullptr;
   float *gc = N > 1 ? grad_c : nullptr;
@@ -1075,10 +1159,16 @@ int bkcore_backward_analytic(const float *a, int64_t lda, const float *b, int64_
       G = Pp;
     }
     int *st = (int *)state;
+    int S = 1;
+    long seg_len = 0;
+    sweep_plan(B, N, S, seg_len);
+    if (S > 1)
+      hipLaunchKernelGGL(bk_adjoint_segsum, dim3((unsigned)(B * S)), dim3(T), 0, s, G, grad_features, grad_G, (long)N,
+                         S, seg_len, segsum, rowbad);
 #define BK_LAUNCH_SWEEPS(OFF)                                                                                         \
-  hipLaunchKernelGGL((bk_adjoint_sweeps<OFF>), dim3((unsigned)B), dim3(T), 0, s, a, (long)lda, b, (long)ldb, c,      \
-                     (long)ldc, z_dev, z_re, z_im, (long)N, G, grad_features, grad_G, grad_a, gk, gc, rowbad, st,      \
-                     (unsigned long long *)sr)
+  hipLaunchKernelGGL((bk_adjoint_sweeps<OFF>), dim3((unsigned)(B * S)), dim3(T), 0, s, a, (long)lda, b, (long)ldb,   \
+                     c, (long)ldc, z_dev, z_re, z_im, (long)N, G, grad_features, grad_G, grad_a, gk, gc, rowbad, st,  \
+                     (unsigned long long *)sr, S, seg_len, (const double2 *)segsum)
     if (flags & BKCORE_FLAG_PHI_EXACT) {
       BK_LAUNCH_SWEEPS(0);
     } else {

@@ -67,7 +67,9 @@ def _case(B, N, seed, dtype=torch.float64):
                                    (2, 6000, 0.3 + 0.5j), (2, 32768, 1j),
                                    # around the kernel's chunk geometry: chunks of 2048 elements advancing by 2032
                                    (2, 2031, 1j), (2, 2032, 1j), (2, 2033, 1j), (2, 2040, 1j), (2, 4064, 1j),
-                                   (2, 4065, 1j), (2, 4079, 1j), (2, 4080, 1j), (2, 4081, 1j), (2, 6112, 0.2 + 1j)])
+                                   (2, 4065, 1j), (2, 4079, 1j), (2, 4080, 1j), (2, 4081, 1j), (2, 6112, 0.2 + 1j),
+                                   # few long rows: several workgroups per row (segments that start two lanes early)
+                                   (2, 40001, 1j), (1, 100003, 0.5 + 1j), (3, 65024, 1j)])
 def test_operator_autograd_matches_adjoint(bk, B, N, z, conv):
     a, b, c, gf, gG = _case(B, N, 7 + N)
     gbar = (gf[..., 0] + 1j * gf[..., 1] + gG).numpy()
@@ -120,6 +122,29 @@ def test_fast_path_is_taken_and_flagged_rows_are_recomputed(bk):
         assert rel(gb[r].cpu().numpy(), rb[r]) <= TOL
         assert rel(gc[r].cpu().numpy(), rc[r]) <= TOL
     assert torch.equal(g2[0], ga[:2])                            # the same numbers with and without a flagged row beside
+
+
+def test_flagged_row_with_several_workgroups_per_row(bk):
+    """The same with rows long and few enough to be cut into segments: any segment's failed check flags the row."""
+    from bkcore import bk_core
+    B, N, z = 3, 50000, 0.05j
+    a, b, c, gf, _ = _case(B, N, 23)
+    a = a - 2.0
+    a[1, 30000:31000] += 2.5
+    gbar = (gf[..., 0] + 1j * gf[..., 1]).numpy()
+    ra, rb, rc, _ = adjoint_grads(a.numpy(), b.numpy(), c.numpy(), z, gbar, "reference")
+    ad, bd, cd = a.float().cuda(), b.float().cuda(), c.float().cuda()
+    _, Gd = bk.bk_forward(ad, bd, cd, z)
+    bk_core._DEBUG["keep_ws"] = True
+    try:
+        ga, gb, gc = bk.bk_backward_analytic(ad, bd, cd, z, gf.float().cuda(), None, G=Gd)
+        assert bk_core.analytic_rows_recomputed() == 1
+    finally:
+        bk_core._DEBUG["keep_ws"] = False
+    for r in range(B):
+        assert rel(ga[r].cpu().numpy(), ra[r]) <= TOL
+        assert rel(gb[r].cpu().numpy(), rb[r]) <= TOL
+        assert rel(gc[r].cpu().numpy(), rc[r]) <= TOL
 
 
 def test_saved_G_and_recomputed_G_agree_and_no_state_block(bk):
