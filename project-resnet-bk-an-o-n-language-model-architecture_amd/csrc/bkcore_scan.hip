@@ -121,46 +121,77 @@ __device__ __forceinline__ float wave_inclusive_scan(float x) {
   return x;
 }
 
-template <bool REVERSE>
+typedef float bk_sv4 __attribute__((ext_vector_type(4)));
+
+// A pass covers RQ blocks of ST quads (4 consecutive elements per thread and block, so that a wave's access is one
+// contiguous kilobyte), scanned side by side with one barrier per pass.  VEC: rows start 16-byte aligned and L is a
+// multiple of 4, so a quad is one 16-byte access (everything is read once and written once: nontemporal).  In reverse
+// mode scan position l is memory position L - 1 - l: a quad's elements are taken in descending order.
+template <bool REVERSE, bool VEC, int RQ>
 __global__ __launch_bounds__(ST) void bk_cumsum_row_kernel(const float *__restrict__ x, float *__restrict__ y, long L) {
-  __shared__ float wtot[2][ST / 64];
+  __shared__ float wtot[2][RQ][ST / 64];
   const float *__restrict__ xp = x + (long)blockIdx.x * L;
   float *__restrict__ yp = y + (long)blockIdx.x * L;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   float carry = 0.0f;
   int buf = 0;
-  for (long l0 = 0; l0 < L; l0 += ST * 4) {
-    const long lb = l0 + (long)t * 4;
-    float v[4];
+  for (long l0 = 0; l0 < L; l0 += (long)ST * 4 * RQ) {
+    float v[RQ][4], incl[RQ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const long l = lb + j;
-      v[j] = l < L ? xp[REVERSE ? L - 1 - l : l] : 0.0f;
+    for (int q = 0; q < RQ; ++q) {
+      const long l = l0 + (long)q * ST * 4 + (long)t * 4;  // first scan position of this thread's quad in block q
+      if (VEC && l + 3 < L) {
+        const bk_sv4 w = __builtin_nontemporal_load(reinterpret_cast<const bk_sv4 *>(xp + (REVERSE ? L - 4 - l : l)));
+        v[q][0] = REVERSE ? w[3] : w[0];
+        v[q][1] = REVERSE ? w[2] : w[1];
+        v[q][2] = REVERSE ? w[1] : w[2];
+        v[q][3] = REVERSE ? w[0] : w[3];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[q][j] = l + j < L ? xp[REVERSE ? L - 1 - (l + j) : l + j] : 0.0f;
+      }
     }
-    v[1] += v[0];
-    v[2] += v[1];
-    v[3] += v[2];
-    const float incl = wave_inclusive_scan(v[3]);
-    if (lane == 63) wtot[buf][wave] = incl;
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      v[q][1] += v[q][0];
+      v[q][2] += v[q][1];
+      v[q][3] += v[q][2];
+      incl[q] = wave_inclusive_scan(v[q][3]);
+      if (lane == 63) wtot[buf][q][wave] = incl[q];
+    }
     __syncthreads();
-    // exclusive prefix of the lane inside its wave: the inclusive scan moved one lane up (0 into lane 0), not
-    // incl - v[3], which is inf - inf = NaN once the lane's own group holds an infinity and loses the prefix by
-    // cancellation when the group is much larger than what came before it
-    const float excl = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(incl), 0x138, 0xF, 0xF, false));
-    float before = carry + excl, all = 0.0f;
+    float running = carry;
 #pragma unroll
-    for (int w = 0; w < ST / 64; ++w) {
-      const float tw = wtot[buf][w];
-      if (w < wave) before += tw;
-      all += tw;
+    for (int q = 0; q < RQ; ++q) {
+      // exclusive prefix of the lane inside its wave: the inclusive scan moved one lane up (0 into lane 0), not
+      // incl - v[3], which is inf - inf = NaN once the lane's own group holds an infinity and loses the prefix by
+      // cancellation when the group is much larger than what came before it
+      const float excl =
+          __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(incl[q]), 0x138, 0xF, 0xF, false));
+      float before = running + excl, all = 0.0f;
+#pragma unroll
+      for (int w = 0; w < ST / 64; ++w) {
+        const float tw = wtot[buf][q][w];
+        if (w < wave) before += tw;
+        all += tw;
+      }
+      running += all;
+      const long l = l0 + (long)q * ST * 4 + (long)t * 4;
+      if (VEC && l + 3 < L) {
+        bk_sv4 w;
+        w[REVERSE ? 3 : 0] = v[q][0] + before;
+        w[REVERSE ? 2 : 1] = v[q][1] + before;
+        w[REVERSE ? 1 : 2] = v[q][2] + before;
+        w[REVERSE ? 0 : 3] = v[q][3] + before;
+        __builtin_nontemporal_store(w, reinterpret_cast<bk_sv4 *>(yp + (REVERSE ? L - 4 - l : l)));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (l + j < L) yp[REVERSE ? L - 1 - (l + j) : l + j] = v[q][j] + before;
+      }
     }
-    carry += all;
+    carry = running;
     buf ^= 1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const long l = lb + j;
-      if (l < L) yp[REVERSE ? L - 1 - l : l] = v[j] + before;
-    }
   }
 }
 
@@ -174,10 +205,18 @@ extern "C" int bkcore_cumsum(const float *x, float *y, int64_t outer, int64_t L,
   hipStream_t s = (hipStream_t)stream;
   if (inner == 1) {
     if (outer > 2147483647LL) return BKCORE_EINVAL;
-    if (reverse)
-      hipLaunchKernelGGL((bk_cumsum_row_kernel<true>), dim3((unsigned)outer), dim3(ST), 0, s, x, y, (long)L);
-    else
-      hipLaunchKernelGGL((bk_cumsum_row_kernel<false>), dim3((unsigned)outer), dim3(ST), 0, s, x, y, (long)L);
+    // 16-byte accesses need aligned rows; long rows take four blocks per pass (a quarter of the barriers)
+    const bool vec = (L % 4) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0;
+#define BK_ROW(REV, VEC, RQ)                                                                                         \
+  hipLaunchKernelGGL((bk_cumsum_row_kernel<REV, VEC, RQ>), dim3((unsigned)outer), dim3(ST), 0, s, x, y, (long)L)
+    if (L >= 4096) {
+      if (reverse) { if (vec) BK_ROW(true, true, 4); else BK_ROW(true, false, 4); }
+      else { if (vec) BK_ROW(false, true, 4); else BK_ROW(false, false, 4); }
+    } else {
+      if (reverse) { if (vec) BK_ROW(true, true, 1); else BK_ROW(true, false, 1); }
+      else { if (vec) BK_ROW(false, true, 1); else BK_ROW(false, false, 1); }
+    }
+#undef BK_ROW
   } else {
     const int64_t col_tiles = (inner + TC - 1) / TC;
     if (outer * col_tiles > 2147483647LL / 64) return BKCORE_EINVAL;

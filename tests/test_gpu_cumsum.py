@@ -15,7 +15,8 @@ def test_cumsum_refuses_cpu_and_bad_args():
 
 
 CASES = [((4, 512, 32), 1), ((8, 2048, 32), 1), ((2, 100, 7), 1), ((3, 8192), -1), ((5, 1000), 1), ((2, 3, 65, 33), 2),
-         ((1, 1, 1), 1), ((6, 1, 40), 1), ((4, 777, 64), 0), ((2, 64, 129), 1), ((1, 70000), -1)]
+         ((1, 1, 1), 1), ((6, 1, 40), 1), ((4, 777, 64), 0), ((2, 64, 129), 1), ((1, 70000), -1),
+         ((3, 4099), -1), ((2, 1001), -1), ((2, 5000), -1)]   # last dim: rows not 16-byte aligned, ragged passes
 
 
 @pytest.mark.gpu
