@@ -30,4 +30,13 @@ res = {"counters": summ,
        "analytic_traffic_bytes_per_launch_corrected": atotal,
        "analytic_traffic_bytes_per_elem_corrected": atotal / (B * N)}
 json.dump(res, open(out_path, "w"), indent=1)
+# the two small files bench.py reads (copied to profiles/ by hand with the rest of the summary)
+import os
+d = os.path.dirname(out_path)
+src = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled per the gfx950 correction"
+json.dump({"rows": B, "seq_len": N, "bytes_per_launch": total, "bytes_per_elem": total / (B * N),
+           "kernel": "bk_ratio_forward_kernel", "source": src}, open(os.path.join(d, "traffic_latest.json"), "w"), indent=1)
+json.dump({"rows": B, "seq_len": N, "analytic_traffic_bytes_per_launch_corrected": atotal,
+           "analytic_traffic_bytes_per_elem_corrected": atotal / (B * N), "kernel": "bk_adjoint_sweeps", "source": src},
+          open(os.path.join(d, "traffic_analytic_latest.json"), "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("forward_traffic_bytes_per_launch_corrected", "forward_traffic_bytes_per_elem_corrected")}))
