@@ -70,3 +70,25 @@ def test_reference_api_surface():
     params = list(inspect.signature(BKCoreFunction.forward).parameters)
     assert params == ["ctx", "he_diag", "h0_super", "h0_sub", "z", "use_triton", "use_parallel_scan"]
     assert bkcore.get_triton_mode() is False
+
+
+def test_launch_failure_reports_the_hip_code_from_every_translation_unit():
+    """Without a GPU every launch fails (hipErrorNoDevice): each entry point must return BKCORE_ELAUNCH and leave the
+    HIP code in bkcore_last_hip_error(), whichever translation unit it lives in.  (Nothing is computed: the launch is
+    refused before any kernel runs.  With a GPU present the test has nothing to provoke and is skipped.)"""
+    import ctypes
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: launches succeed")
+    L = _lib.load()
+    buf = (ctypes.c_float * 256)()
+    p = ctypes.addressof(buf)
+    calls = {
+        "bkcore_backward_ref (bkcore_kernels.hip)": lambda: L.bkcore_backward_ref(p, p, None, 0.5, 4, p, None),
+        "bkcore_cumsum (bkcore_scan.hip)": lambda: L.bkcore_cumsum(p, p, 1, 16, 1, 0, None),
+        "bkcore_layer_epilogue (bkcore_layer.hip)": lambda: L.bkcore_layer_epilogue(p, p, p, p, None, 2, 4, p, None),
+    }
+    for name, call in calls.items():
+        rc = call()
+        assert rc == _lib.ELAUNCH, name
+        assert L.bkcore_last_hip_error() != 0, name
