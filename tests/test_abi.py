@@ -76,8 +76,8 @@ def test_launch_failure_reports_the_hip_code_from_every_translation_unit():
     """Without a GPU every launch fails (hipErrorNoDevice): each entry point must return BKCORE_ELAUNCH and leave the
     HIP code in bkcore_last_hip_error(), whichever translation unit it lives in.  (Nothing is computed: the launch is
     refused before any kernel runs.  With a GPU present the test has nothing to provoke and is skipped.)"""
-    import ctypes
     import torch
+    from bkcore import _lib
     if torch.cuda.is_available():
         pytest.skip("a GPU is present: launches succeed")
     L = _lib.load()
