@@ -46,6 +46,13 @@ extern "C" {
                                    * Which kernel computes a well-conditioned row then depends on the calls before it: the
                                    * two kernels agree to the operator's tolerance, not bit for bit. */
 
+#define BKCORE_FLAG_ROW_UNITS 16u  /* diagnostics: cut every row into two units (with BKCORE_FLAG_ROW_UNITS_MANY, 32u: into
+                                    * as many units of two chunks as it has) that hand the running product on inside the
+                                    * first launch.  The library does this by itself, two units a row, when there are more
+                                    * rows than the GPU holds workgroups at once but fewer than three times as many; the
+                                    * flags force it for any row count.  Bit for bit the results of whole rows. */
+#define BKCORE_FLAG_ROW_UNITS_MANY 32u
+
 /* error codes */
 #define BKCORE_OK 0
 #define BKCORE_EINVAL (-1)   /* bad argument (null pointer, negative size, unknown dtype) */

@@ -14,8 +14,10 @@ FLAG_RAW = 1
 FLAG_PHI_EXACT = 2
 FLAG_SCAN_PATH = 4
 FLAG_ADAPTIVE = 8
+FLAG_ROW_UNITS = 16
+FLAG_ROW_UNITS_MANY = 32
 STATE_BYTES = 64
-ABI_VERSION = 13
+ABI_VERSION = 14
 EINVAL, ETOOLONG, ELAUNCH, EWORKSPACE, ETOOBIG = -1, -2, -3, -4, -5
 BWD_REFERENCE, BWD_BATCHED, BWD_SCAN_STABLE = 0, 1, 2
 NOALLOC_MAX_WORKSPACE = 8 << 20

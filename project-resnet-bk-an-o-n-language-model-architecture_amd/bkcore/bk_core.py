@@ -26,7 +26,7 @@ from . import _lib
 logger = logging.getLogger(__name__)
 
 _DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16, torch.float64: _lib.F64}
-_DEBUG = {"keep_ws": False, "last_ws": None, "last_B": 0, "scan_path": False}  # diagnostics: see rows_recomputed()
+_DEBUG = {"keep_ws": False, "last_ws": None, "last_B": 0, "scan_path": False, "row_units": 0}  # diagnostics: see rows_recomputed()
 _state = {}  # (device index, stream handle) -> persistent int32 state block for the NaN-sanitiser corner
 _ws = {}     # (device index, stream handle) -> workspace tensor, grown on demand and reused by every call on the stream
 _ws_bytes = {}  # (B, N) -> bkcore_workspace_bytes(B, N)
@@ -163,7 +163,7 @@ def bk_forward(a, b, c, z, raw: bool = False, phi_exact: bool = False, want_feat
         state = _state_block(dev, stream)
         flags = (_lib.FLAG_RAW if raw else 0) | (_lib.FLAG_PHI_EXACT if phi_exact else 0) \
             | (_lib.FLAG_SCAN_PATH if _DEBUG["scan_path"] else 0) \
-            | (_lib.FLAG_ADAPTIVE if BKCoreFunction.ADAPTIVE_PATH else 0)
+            | (_lib.FLAG_ADAPTIVE if BKCoreFunction.ADAPTIVE_PATH else 0) | _DEBUG["row_units"]
         ws, ws_bytes = _workspace(L, dev, stream, B, N)
         if _DEBUG["keep_ws"]:       # diagnostics read the workspace after the call: give this call its own
             ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)

@@ -551,8 +551,10 @@ __device__ __forceinline__ void sweepB_range(const TIn *__restrict__ a, const TI
 
 // The state block: state[0] a NaN was seen in he_diag, state[1] a NaN was seen in b or c, state[2] some row failed its
 // checks -- raised (to 1) by the first launch(es) of a call, read by every workgroup of the call's last launch, which
-// is always the second-launch form of bk_forward_kernel.  Clean calls leave the block all zero and cost nothing.  When
-// a flag is up, every workgroup of that last launch takes a ticket in state[4] once it has read the flags and done its
+// is always the second-launch form of bk_forward_kernel.  Clean calls leave these all zero and cost nothing.
+// state[9] counts the first launches that cut rows into units handing over inside the launch (the epoch their records
+// are tagged with; moved on by the call's last launch), state[12] says that such a hand-over was given up and every
+// row is to be recomputed.  When a flag is up, every workgroup of that last launch takes a ticket in state[4] once it has read the flags and done its
 // work, and the last ticket puts the block back to zero for the next call on the stream.  All of it lives on the
 // device, so a captured forward replays correctly in a HIP graph.
 __device__ __forceinline__ void state_release(int *state, bool redone = false, bool adaptive = false) {
@@ -575,6 +577,7 @@ __device__ __forceinline__ void state_release(int *state, bool redone = false, b
       __hip_atomic_store(&state[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&state[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&state[4], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&state[12], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -600,9 +603,15 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
     const int sa = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int sb = __hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int sc = __hip_atomic_load(&state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!(sa | sb | sc)) return;  // nothing was flagged by the first launch: the usual case
+    // state[12]: a hand-off inside the first launch was given up (rows cut into units of one launch): every row again
+    const int sd = __hip_atomic_load(&state[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // second == 2: the first launch cut rows into units that hand over inside the launch and tag their records with
+    // the epoch in state[9]; the next launch needs a new one
+    if (second == 2 && blockIdx.x == 0 && threadIdx.x == 0)
+      __hip_atomic_fetch_add(&state[9], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!(sa | sb | sc | sd)) return;  // nothing was flagged by the first launch: the usual case
     fix_bc = (sa != 0 && sb != 0) && !(flags & BKCORE_FLAG_RAW);
-    const bool redo_row = sc != 0 && rowflag[row] != 0;
+    const bool redo_row = sd != 0 || (sc != 0 && rowflag[row] != 0);
     if (!fix_bc && !redo_row) {
       state_release(state, false, (flags & BKCORE_FLAG_ADAPTIVE) != 0);
       return;
@@ -1308,6 +1317,42 @@ inline void split_plan(int64_t B, int64_t N, int chunk, int &S, int &seg_ch) {
   S = (nch + seg_ch - 1) / seg_ch;
 }
 
+// Many rows, one launch (mode 3 of the ratio-form kernel): with more rows than the GPU holds workgroups at once, whole
+// rows leave a last round in which most CUs hold a single workgroup (1024 rows on 3 x 256 places: the launch lasts
+// about 1.55 row times where 1.33 would do).  Rows cut into S units of seg_ch chunks that hand the running product on
+// inside the launch fill that round evenly.  S = 1: keep one workgroup per row.
+inline int device_cu_count() {
+  static int cus[MAX_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return 256;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+inline void relay_plan(int64_t B, int64_t N, int chunk, int wgs_per_cu, unsigned flags, int &S, int &seg_ch) {
+  const int nch = (int)((N + chunk - 1) / chunk);
+  S = 1;
+  seg_ch = nch;
+  // development: BKCORE_RELAY_UNITS=S in the environment asks for S units whatever the row count (0: never)
+  static const int from_env = [] { const char *e = getenv("BKCORE_RELAY_UNITS"); return e ? atoi(e) : -1; }();
+  int forced = from_env;
+  if (flags & BKCORE_FLAG_ROW_UNITS_MANY) forced = nch / 2;
+  else if (flags & BKCORE_FLAG_ROW_UNITS) forced = 2;
+  int want = forced >= 0 ? forced : 2;
+  // Worth it from the first row that does not fit the GPU at once up to about three rounds of rows: beyond that the
+  // last round is a small part of the launch and the extra workgroup starts cost more than it loses (measured at
+  // 8192 rows: 1.18 ms whole rows, 1.22 ms in units).
+  const int64_t places = (int64_t)wgs_per_cu * device_cu_count();
+  if (want < 2 || nch < 4 || (forced < 0 && (B <= places || B >= 3 * places))) return;
+  if (want > nch / 2) want = nch / 2;  // at least two chunks per unit
+  seg_ch = (nch + want - 1) / want;
+  S = (nch + seg_ch - 1) / seg_ch;
+  if (B * S > 2147483647LL) { S = 1; seg_ch = nch; }
+}
+
 template <typename TIn>
 constexpr int dtype_tag() {
   return std::is_same<TIn, float>::value ? BKCORE_F32
@@ -1373,11 +1418,19 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
     // single-sweep ratio-form first launch, then the (normally empty) second launch for rows whose checks failed
     const auto fwd = (N > BKCORE_INTERNAL_LONG_ROW && !SAVE) ? bkcore_internal_ratio_forward_long
                                                              : bkcore_internal_ratio_forward;
-    fwd(dtype_tag<TIn>(), PHI_EXACT, 0, SAVE, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
-        flags, fclamp, 1, 0, save_r, save_s, stream);
+    int RS = 1, rseg = 0;
+    if (!SAVE && N <= BKCORE_INTERNAL_LONG_ROW && !(flags & BKCORE_FLAG_ADAPTIVE))
+      relay_plan(B, N, bkcore_internal_ratio_chunk(), sizeof(TIn) == 2 ? 2 : 3, flags, RS, rseg);
+    if (RS > 1)
+      fwd(dtype_tag<TIn>(), PHI_EXACT, 3, 0, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
+          flags, fclamp, RS, rseg, nullptr, nullptr, stream);
+    else
+      fwd(dtype_tag<TIn>(), PHI_EXACT, 0, SAVE, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
+          flags, fclamp, 1, 0, save_r, save_s, stream);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) {
-      BK_LAUNCH(false, 1);
+      if (RS > 1) BK_LAUNCH(false, 2);
+      else BK_LAUNCH(false, 1);
       err = hipGetLastError();
     }
     if (err != hipSuccess) {
@@ -1678,7 +1731,7 @@ int bkcore_layer_backward_ref(const float *G, const float *grad_features, const 
 int64_t bkcore_max_seq_len(void) { return (int64_t)MAX_N; }
 int bkcore_last_hip_error(void) { return g_last_hip_error; }
 void bkcore_internal_set_hip_error(int code) { g_last_hip_error = code; }
-int bkcore_abi_version(void) { return 13; }
+int bkcore_abi_version(void) { return 14; }
 
 const char *bkcore_error_string(int code) {
   switch (code) {

@@ -87,6 +87,15 @@ static_assert(RT % 64 == 0 && RT >= 64 && RT <= 256, "whole waves, at most the s
 #ifndef BK_RATIO_EXPERIMENT
 #define BK_RATIO_EXPERIMENT 0
 #endif
+#ifndef BK_RELAY_DEBUG
+#define BK_RELAY_DEBUG 0      // development: poll statistics of the in-launch hand-off in state[13..15]
+#endif
+#ifndef BK_UNIT_STAMPS
+#define BK_UNIT_STAMPS 0      // development: per workgroup start / end wall clock and hardware id, 32 bytes each, 8 MiB
+#endif                        // into the lane-state region of the workspace (tools/dev_units.py)
+#ifndef BK_RELAY_NOWAIT
+#define BK_RELAY_NOWAIT 0     // development: no hand-off at all (wrong results; the cost of everything else)
+#endif
 #ifndef BK_RATIO_PREFETCH
 #define BK_RATIO_PREFETCH 1   // raw inputs of the next chunk held in registers during the current chunk's arithmetic
 #endif
@@ -177,6 +186,22 @@ struct SharedR {
   Prod tot[2][RWAVES];
   Prod carry[2];
 };
+
+// MODE 3 hand-off between the workgroups of one row, all in ONE launch.  A record of RELAY_REC floats per (row,
+// segment) in the lane-state region of the workspace (the ratio form keeps no lane states; the scan kernel of the
+// second launch rewrites that region before it reads it): [0,1] mantissa and [2] exponent of the running product
+// after the segment, [4..7] the edge values of its leftmost lane, [8,9] a 64-bit tag that says "written during this
+// launch".  The tag is derived from a per-launch epoch kept in the state block, so whatever another owner of the
+// memory left in the record cannot pass for a hand-off (a foreign value would have to equal a 64-bit hash of the
+// current epoch), and the reader of a record takes its tag down, so neither can what an earlier launch left.
+constexpr int RELAY_REC = 16;
+constexpr int ST_EPOCH = 9, ST_REDO_ALL = 12;  // ints of the state block used by MODE 3
+constexpr long long RELAY_WAIT_TICKS = 5000000;  // of the 100 MHz wall clock: 50 ms before a unit gives the launch up
+__device__ __forceinline__ unsigned long long relay_tag(int epoch, long unit) {
+  unsigned long long x = ((unsigned long long)(unsigned)epoch << 32) ^ (unsigned long long)unit ^ 0x9E3779B97F4A7C15ull;
+  x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 29; x *= 0x94D049BB133111EBull; x ^= x >> 32;
+  return x | 1ull;
+}
 
 __device__ __forceinline__ int rpad16(int q) { return q + q / E; }  // lane stride E + 1 entries
 // staged slot q0 + d of a lane whose first slot q0 is a multiple of 16: base + roff(d), d a compile-time constant
@@ -302,8 +327,8 @@ __device__ __forceinline__ bool differs_tight(float2 p, float2 q) {
 constexpr int RNJ = E + 1;
 template <typename TIn>
 __device__ __forceinline__ void load_ratio(const TIn *__restrict__ a, const TIn *__restrict__ b,
-                                           const TIn *__restrict__ c, long base, long N, bool full, float (&av)[RNJ],
-                                           float (&bv)[RNJ], float (&cv)[RNJ]) {
+                                           const TIn *__restrict__ c, long base, long N, bool full, bool left_open,
+                                           float (&av)[RNJ], float (&bv)[RNJ], float (&cv)[RNJ]) {
   const int t = threadIdx.x;
   // 32-bit offsets from uniform bases (scalar base + vector offset addressing); slot q holds element base - RH + q
   const TIn *__restrict__ a0 = a + (base - RH);
@@ -320,9 +345,10 @@ __device__ __forceinline__ void load_ratio(const TIn *__restrict__ a, const TIn 
   } else {
     // branch-free: every load uses a clamped, always valid index (b and c must be readable at index 0 even when the
     // row has no off-diagonal: the caller passes `a` for them then); out-of-row values are replaced afterwards
-    const int lo_a = (int)max(0L, RH - base);                  // first slot whose element index is >= 0
+    // (left_open: the row continues to the left of index 0, only its right end bounds the loads)
+    const int lo_a = left_open ? 0 : (int)max(0L, RH - base);  // first slot whose element index is >= 0
     const int hi_a = (int)min((long)RN, N - 1 - (base - RH));  // last slot whose element index is <= N-1 (may be < lo)
-    const int lo_k = (int)max(0L, RH + 1 - base);              // k index = element index - 1 >= 0
+    const int lo_k = left_open ? 0 : (int)max(0L, RH + 1 - base);  // k index = element index - 1 >= 0
     const int hi_k = (int)min((long)RN, N - 2 - (base - RH - 1));
     const int ca = max(hi_a, lo_a), ck = max(hi_k, lo_k);
 #pragma unroll
@@ -331,8 +357,8 @@ __device__ __forceinline__ void load_ratio(const TIn *__restrict__ a, const TIn 
       const int qa = min(max(q, lo_a), ca);
       const int qk = min(max(q, lo_k), ck);
       const float va = to_f32<TIn>(a0[qa]);
-      const float vb = to_f32<TIn>(b0[N >= 2 ? qk : qa + 1]);
-      const float vc = to_f32<TIn>(c0[N >= 2 ? qk : qa + 1]);
+      const float vb = to_f32<TIn>(b0[(N >= 2 || left_open) ? qk : qa + 1]);
+      const float vc = to_f32<TIn>(c0[(N >= 2 || left_open) ? qk : qa + 1]);
       av[j] = (q >= lo_a && q <= hi_a) ? va : 1.0f;
       bv[j] = (q >= lo_k && q <= hi_k) ? vb : 0.0f;
       cv[j] = (q >= lo_k && q <= hi_k) ? vc : 0.0f;
@@ -417,25 +443,41 @@ __device__ __forceinline__ unsigned commit_ratio(const RowCfg &cfg, const float 
 // SAVE (MODE 0 only, for the analytic backward): also stores r_j and s_j, and writes G_raw (before the final
 // log-magnitude clamp and the clip; 0 outside 1e-18 <= |G_raw| <= 1e18) instead of G.
 template <typename TIn, bool PHI_EXACT, int MODE, bool SAVE = false>
-__global__ __launch_bounds__(RT, (MODE == 0 && !SAVE && !LONG && sizeof(TIn) != 2) ? BK_RATIO_WAVES : 2) void bk_ratio_forward_kernel(
+__global__ __launch_bounds__(RT, ((MODE == 0 || MODE == 3) && !SAVE && !LONG && sizeof(TIn) != 2) ? BK_RATIO_WAVES : 2) void bk_ratio_forward_kernel(
     const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
-    const float *__restrict__ z_dev, float z_re, float z_im, long B, long N, float2 *__restrict__ G_,
+    const float *__restrict__ z_dev, float z_re, float z_im, long B, long N_, float2 *__restrict__ G_,
     float2 *__restrict__ F_, char *__restrict__ ws, int *state, unsigned flags, float fclamp, int S,
     int seg_ch, float2 *__restrict__ save_r_ = nullptr, float2 *__restrict__ save_s_ = nullptr) {
   __shared__ SharedR sh;
-  const long row = MODE == 0 ? (long)blockIdx.x : (long)(blockIdx.x / S);
-  const int sg = MODE == 0 ? 0 : (int)(blockIdx.x % S);
+  constexpr bool RELAY = MODE == 3;
+  long row = MODE == 0 ? (long)blockIdx.x : (long)(blockIdx.x / S);
+  int sg = MODE == 0 ? 0 : (int)(blockIdx.x % S);
+  if (RELAY) {
+    // Units in workgroup order, the rightmost segments of all rows first: the unit a workgroup depends on (same row,
+    // the segment to the right) has an index lower by B.  The hardware starts workgroups in index order, so that unit
+    // is running or done, and rightmost segments wait for nothing: the lowest unfinished unit can always proceed.
+    // (Should a wait outlast RELAY_WAIT_TICKS all the same, the unit gives up and the second launch recomputes
+    // every row.)
+    row = (long)(blockIdx.x % (unsigned)B);
+    sg = S - 1 - (int)(blockIdx.x / (unsigned)B);
+  }
   int *rowflag = reinterpret_cast<int *>(ws);
   if (MODE == 2 && rowflag[row] != 0) return;  // the whole row is recomputed by the scan kernel
-  const TIn *a = a_ + row * lda;
-  const TIn *b = N >= 2 ? b_ + row * ldb : a;  // never used for data when N == 1, but must be readable
-  const TIn *c = N >= 2 ? c_ + row * ldc : a;
-  float2 *G = G_ + row * N;
-  float2 *F = F_ ? F_ + row * N : nullptr;
+  // MODE 3 works in coordinates that start at the unit's first chunk (element index, row length and chunk numbers
+  // all count from there; what lies to the left is reachable through `left_open`): the chunk loop then is the loop
+  // of MODE 0, which is what fits the register budget of three workgroups per CU.
+  const long shift = RELAY ? (long)sg * seg_ch * RCHUNK : 0;
+  const bool left_open = RELAY && sg > 0;  // the elements before index 0 belong to the row
+  const long N = N_ - shift;
+  const TIn *a = a_ + row * lda + shift;
+  const TIn *b = N_ >= 2 ? b_ + row * ldb + shift : a;  // never used for data when N == 1, but must be readable
+  const TIn *c = N_ >= 2 ? c_ + row * ldc + shift : a;
+  float2 *G = G_ + row * N_ + shift;
+  float2 *F = F_ ? F_ + row * N_ + shift : nullptr;
   const int nch = (int)((N + RCHUNK - 1) / RCHUNK);
-  const int ch0 = MODE == 0 ? 0 : sg * seg_ch;
+  const int ch0 = (MODE == 0 || RELAY) ? 0 : sg * seg_ch;
   const int ch1 = MODE == 0 ? nch : min(nch, ch0 + seg_ch);
-  float *info = reinterpret_cast<float *>(ws + rowflag_bytes(B) + lane_state_bytes(B, N)) + (row * S + sg) * SEG_INFO;
+  float *info = reinterpret_cast<float *>(ws + rowflag_bytes(B) + lane_state_bytes(B, N_)) + (row * S + sg) * SEG_INFO;
   RowCfg cfg;
   cfg.z = z_dev ? make_float2(z_dev[0], z_dev[1]) : make_float2(z_re, z_im);
   cfg.N = N;
@@ -466,12 +508,58 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE && !LONG && sizeof(TIn) != 
   // (2 waves per SIMD).
   // 16-bit operands (the layer's bfloat16 diagonal) measured faster with two workgroups per CU and the prefetch:
   // twice the load instructions per byte
-  constexpr bool PREFETCH = !(MODE == 0 && !SAVE && BK_RATIO_WAVES >= 3 && sizeof(TIn) != 2) && !LONG && BK_RATIO_PREFETCH;
+  constexpr bool PREFETCH = !((MODE == 0 || MODE == 3) && !SAVE && BK_RATIO_WAVES >= 3 && sizeof(TIn) != 2) && !LONG && BK_RATIO_PREFETCH;
   float av[RNJ], bv[RNJ], cv[RNJ];
   auto prefetch = [&](int ch) __attribute__((always_inline)) {
     // `full`: the chunk and its halos (and the one extra k) lie inside the row
-    load_ratio<TIn>(a, b, c, (long)ch * RCHUNK, N, ch >= 1 && (long)(ch + 1) * RCHUNK + RH + 1 <= N, av, bv, cv);
+    load_ratio<TIn>(a, b, c, (long)ch * RCHUNK, N, (ch >= 1 || left_open) && (long)(ch + 1) * RCHUNK + RH + 1 <= N,
+                    left_open, av, bv, cv);
   };
+  if (RELAY) {
+    if (!BK_RELAY_NOWAIT && sg < S - 1 && t == 0) {
+      // a segment that has a right neighbour starts from that neighbour's running product and edge values (carry[0]
+      // and edge[1] are the slots the first chunk reads)
+      const float *src = reinterpret_cast<const float *>(ws + rowflag_bytes(B)) + (row * S + sg + 1) * RELAY_REC;
+      const int epoch = __hip_atomic_load(&state[ST_EPOCH], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long want = relay_tag(epoch, row * S + sg + 1);
+      const unsigned long long *tagp = reinterpret_cast<const unsigned long long *>(src + 8);
+      // Every access to a record is an agent-scope atomic (served at the level all CUs share), ordered by waiting for
+      // the memory counter: no acquire / release fences, which on this GPU write back and invalidate the whole L2.
+      bool got = __hip_atomic_load(tagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
+      if (!got) {
+        const long long t0 = wall_clock64();
+#if BK_RELAY_DEBUG
+        __hip_atomic_fetch_add(&state[15], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+#pragma unroll 1
+        while (!got && wall_clock64() - t0 < RELAY_WAIT_TICKS) {
+          __builtin_amdgcn_s_sleep(8);
+          got = __hip_atomic_load(tagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
+        }
+#if BK_RELAY_DEBUG
+        __hip_atomic_fetch_max(&state[14], (int)(wall_clock64() - t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record is read only after its tag has been seen
+      if (!got) {
+        // never expected; the second launch then recomputes every row, so nothing of this launch is used
+        __hip_atomic_store(&state[ST_REDO_ALL], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        Prod p;
+        p.m = c2((Real)__hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                 (Real)__hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        p.e = __float_as_int(__hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        sh.carry[0] = p;
+        sh.edge[1] = make_float4(__hip_atomic_load(src + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                 __hip_atomic_load(src + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                 __hip_atomic_load(src + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                 __hip_atomic_load(src + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        // A record has one reader, who takes the tag down again: the next launch finds no tag of this one even if
+        // its epoch is the same (a state block that was zeroed again, e.g. by the memset of a replayed graph).
+        __hip_atomic_store(const_cast<unsigned long long *>(tagp), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
   auto one = [&](auto tail, int ch) __attribute__((always_inline)) {
     constexpr bool TAIL = decltype(tail)::value;
     const long base = (long)ch * RCHUNK;
@@ -644,7 +732,7 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE && !LONG && sizeof(TIn) != 
     {
       float4 nb = nbv;  // thread t-1's (theta warm-up, phi end) inside the wave
       if (lane == 0) nb = wave > 0 ? sh.wedge[buf][wave - 1] : sh.edge[buf ^ 1];
-      if (t > 0 || ch < ch1 - 1) {
+      if (t > 0 || ch < (RELAY ? nch : ch1) - 1) {
         bad |= differs_tight(make_float2(nb.x, nb.y), th_fin);
         bad |= differs_tight(ph_west, make_float2(nb.z, nb.w));
       }
@@ -750,6 +838,13 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE && !LONG && sizeof(TIn) != 
   // development: start the workgroups at different phases of the chunk period
   for (int i = (int)((blockIdx.x * 2654435761u) >> 28); i > 0; --i) __builtin_amdgcn_s_sleep(BK_RATIO_STAGGER);
 #endif
+#if BK_UNIT_STAMPS
+  unsigned long long *ustamp = reinterpret_cast<unsigned long long *>(ws + rowflag_bytes(B) + (8u << 20)) + 4 * (size_t)blockIdx.x;
+  if (threadIdx.x == 0) {
+    ustamp[0] = wall_clock64();
+    ustamp[2] = ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | (unsigned)__builtin_amdgcn_s_getreg(0xF804);
+  }
+#endif
   // chunk kinds: those within reach of a halo of the end of the row (the last one or two), then the others
   if (skip_arith) {  // uniform over the grid: stage every chunk for its NaN verdicts, nothing else
 #pragma unroll 1
@@ -771,10 +866,40 @@ __global__ __launch_bounds__(RT, (MODE == 0 && !SAVE && !LONG && sizeof(TIn) != 
     reinterpret_cast<unsigned long long *>(ws + rowflag_bytes(B))[(row * nch) * 16 + 15] = wall_clock64();
 #endif
   const int any_bad = __syncthreads_or(bad ? 1 : 0);
+#if BK_UNIT_STAMPS
+  if (threadIdx.x == 0) ustamp[1] = wall_clock64();
+#endif
   if (t == 0) {
     if (MODE == 0) {
       rowflag[row] = any_bad;
       if (any_bad) __hip_atomic_store(&state[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (RELAY) {
+      // (which unit this is, worked out again rather than kept in scalar registers across the chunk loop: the kernel
+      // has none to spare)
+      const long row = (long)(blockIdx.x % (unsigned)B);
+      const int sg = S - 1 - (int)(blockIdx.x / (unsigned)B);
+      const int epoch = __hip_atomic_load(&state[ST_EPOCH], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float *relay = reinterpret_cast<float *>(ws + rowflag_bytes(B)) + (row * S + sg) * RELAY_REC;
+      // The row's verdict: the rightmost segment stores it before it publishes its record, the others have acquired
+      // that record (directly or through the segments between) before they add to it.
+      if (sg == S - 1) __hip_atomic_store(&rowflag[row], any_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if (any_bad) __hip_atomic_fetch_or(&rowflag[row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (any_bad) __hip_atomic_store(&state[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (sg > 0) {
+        const Prod p = sh.carry[nscan & 1];
+        const float4 ed = sh.edge[(nscan & 1) ^ 1];  // written in the segment's last (leftmost) chunk
+        __hip_atomic_store(relay + 0, (float)p.m.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(relay + 1, (float)p.m.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(relay + 2, __int_as_float(p.e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(relay + 4, ed.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(relay + 5, ed.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(relay + 6, ed.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(relay + 7, ed.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record (and the row's verdict) before its tag
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(relay + 8), relay_tag(epoch, row * S + sg),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // (the epoch moves on in the call's last launch, which every MODE 3 launch is followed by)
     } else if (MODE == 1) {
       put_prod(info, 0, 16, 2, sh.carry[nscan & 1]);  // started from one: the segment's own product
       info[3] = any_bad ? 1.0f : 0.0f;
@@ -858,6 +983,9 @@ void ratio_launch(int mode, int save, const void *a, long lda, const void *b, lo
                      (float2 *)save_r, (float2 *)save_s)
   if (mode == 1) BK_RATIO(1, false, B * S);
   else if (mode == 2) BK_RATIO(2, false, B * S);
+#if !BK_RATIO_LONG
+  else if (mode == 3) BK_RATIO(3, false, B * S);
+#endif
   else if (!save) BK_RATIO(0, false, B);
 #if !BK_RATIO_LONG
   else if (std::is_same<TIn, float>::value) BK_RATIO(0, true, B);  // the saving variant exists for float32 operands
