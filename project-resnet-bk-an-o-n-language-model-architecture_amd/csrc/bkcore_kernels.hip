@@ -1345,8 +1345,12 @@ inline void relay_plan(int64_t B, int64_t N, int chunk, int wgs_per_cu, unsigned
   // Worth it from the first row that does not fit the GPU at once up to about three rounds of rows: beyond that the
   // last round is a small part of the launch and the extra workgroup starts cost more than it loses (measured at
   // 8192 rows: 1.18 ms whole rows, 1.22 ms in units).
+  // Nor when the last round is full or nearly so (16-bit operands run two workgroups per CU: 1024 rows are exactly
+  // two rounds of 512).
   const int64_t places = (int64_t)wgs_per_cu * device_cu_count();
-  if (want < 2 || nch < 4 || (forced < 0 && (B <= places || B >= 3 * places))) return;
+  const int64_t last = B % places;
+  if (want < 2 || nch < 4 || (forced < 0 && (B <= places || B >= 3 * places || last == 0 || 4 * last > 3 * places)))
+    return;
   if (want > nch / 2) want = nch / 2;  // at least two chunks per unit
   seg_ch = (nch + want - 1) / want;
   S = (nch + seg_ch - 1) / seg_ch;
