@@ -62,6 +62,17 @@ def test_headline_forward_fits_three_workgroups_per_cu(kernels):
         assert 3 * r["group_segment_fixed_size"] <= 160 * 1024, r
 
 
+def test_forward_in_units_keeps_the_same_budget(kernels):
+    # bk_ratio_forward_kernel<float, PHI_EXACT, MODE 3, SAVE false>: rows cut into units of one launch run the chunk
+    # loop of MODE 0; a formulation that keeps one more scalar alive across that loop spills 30-100 dwords
+    hits = _find(kernels, "bk_ratio_forward_kernelIfLb", "ELi3ELb0E")
+    assert len(hits) == 2, hits
+    for k in hits:
+        r = kernels[k]
+        assert r["vgpr_count"] <= 168 and r["private_segment_fixed_size"] <= 16, (k, r)
+        assert 3 * r["group_segment_fixed_size"] <= 160 * 1024, (k, r)
+
+
 def test_one_pass_analytic_backward_does_not_spill(kernels):
     for k in _find(kernels, "bk_adjoint_sweeps"):
         r = kernels[k]
