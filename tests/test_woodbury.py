@@ -64,7 +64,10 @@ def test_woodbury_matches_reference_outputs():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,N,r", [(1, 1, 1), (5, 100, 7), (3, 5000, 13), (2, 70000, 17), (130, 300, 22), (4, 64, 0)])
+# (at least 16 rows and rank <= 16: the matrix-core forms of the two O(N r^2) passes; otherwise the vector forms)
+@pytest.mark.parametrize("B,N,r", [(1, 1, 1), (5, 100, 7), (3, 5000, 13), (2, 70000, 17), (130, 300, 22), (4, 64, 0),
+                                   (16, 64, 16), (17, 1, 1), (70, 5000, 13), (64, 3001, 16), (33, 1030, 1),
+                                   (200, 777, 9), (129, 2049, 8), (40, 4100, 15)])
 def test_woodbury_matches_float64_loop(B, N, r):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
