@@ -52,6 +52,9 @@ extern "C" {
                                     * rows than the GPU holds workgroups at once but fewer than three times as many; the
                                     * flags force it for any row count.  Bit for bit the results of whole rows. */
 #define BKCORE_FLAG_ROW_UNITS_MANY 32u
+#define BKCORE_FLAG_ROW_UNITS_MUTE 64u /* diagnostics, with one of the two above: the units do not publish their records, so
+                                    * every unit that waits for one gives up after 50 ms and the call's last launch
+                                    * recomputes every row (exercises that recovery; same results within the tolerance) */
 
 /* error codes */
 #define BKCORE_OK 0

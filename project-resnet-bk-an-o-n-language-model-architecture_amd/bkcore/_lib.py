@@ -16,6 +16,7 @@ FLAG_SCAN_PATH = 4
 FLAG_ADAPTIVE = 8
 FLAG_ROW_UNITS = 16
 FLAG_ROW_UNITS_MANY = 32
+FLAG_ROW_UNITS_MUTE = 64
 STATE_BYTES = 64
 ABI_VERSION = 14
 EINVAL, ETOOLONG, ELAUNCH, EWORKSPACE, ETOOBIG = -1, -2, -3, -4, -5

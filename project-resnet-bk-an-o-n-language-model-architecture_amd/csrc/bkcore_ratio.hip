@@ -885,7 +885,7 @@ __global__ __launch_bounds__(RT, ((MODE == 0 || MODE == 3) && !SAVE && !LONG && 
       if (sg == S - 1) __hip_atomic_store(&rowflag[row], any_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else if (any_bad) __hip_atomic_fetch_or(&rowflag[row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (any_bad) __hip_atomic_store(&state[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (sg > 0) {
+      if (sg > 0 && !(flags & BKCORE_FLAG_ROW_UNITS_MUTE)) {
         const Prod p = sh.carry[nscan & 1];
         const float4 ed = sh.edge[(nscan & 1) ^ 1];  // written in the segment's last (leftmost) chunk
         __hip_atomic_store(relay + 0, (float)p.m.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

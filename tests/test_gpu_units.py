@@ -180,3 +180,38 @@ def test_units_graph_replay(bk, own_state):
     for a_k, G_k in outs:
         _, G_e = bk.bk_forward(a_k, b, c, z)
         assert torch.equal(torch.view_as_real(G_e), torch.view_as_real(G_k))
+
+
+def test_units_give_up_and_recover(bk):
+    """BKCORE_FLAG_ROW_UNITS_MUTE: no unit publishes its record, so every left unit gives its wait up (50 ms), the
+    launch raises the recompute-everything flag, and the call's last launch redoes every row on the two-scan path:
+    the results are that path's (the operator's tolerance from the oracle), the state block is left clean, and the
+    next call is an ordinary one."""
+    import time
+    from bkcore import bk_core
+    from oracle import bk_oracle_c as C
+    B, N = 20, 4 * CH + 77
+    a, b, c = _inputs(B, N, seed=11, varying=True)
+    z = 0.3 + 0.9j
+    bk_core._DEBUG["row_units"] = 16 | 64
+    torch.cuda.synchronize()
+    t0 = time.time()
+    _, G = bk.bk_forward(a, b, c, z)
+    torch.cuda.synchronize()
+    waited = time.time() - t0
+    bk_core._DEBUG["row_units"] = 0
+    assert 0.04 <= waited <= 5.0, waited
+    st = bk_core._state_block(a.device, torch.cuda.current_stream().cuda_stream).tolist()
+    assert st[:9] == [0] * 9 and st[12] == 0
+    ref = C.get_diag(a.cpu().numpy(), b.cpu().numpy(), c.cpu().numpy(), z)
+    assert float(np.max(np.abs(G.cpu().numpy() - ref) / np.abs(ref))) <= 1e-4
+    bk_core._DEBUG["scan_path"] = True          # every row from the scan kernels: what the recovery ran
+    try:
+        _, Gs = bk.bk_forward(a, b, c, z)
+    finally:
+        bk_core._DEBUG["scan_path"] = False
+    # (the scan path's first launch is its fast form, the recovery its two-scan form: same tolerance, not bitwise)
+    assert float((G - Gs).abs().max() / Gs.abs().max()) <= 1e-4
+    (f0, G0, r0), (f1, G1, r1) = _both(bk, 16, a, b, c, z)  # and the units work again right after
+    assert r0 == 0 and r1 == 0
+    assert torch.equal(torch.view_as_real(G0), torch.view_as_real(G1))
