@@ -20,6 +20,8 @@ extern "C" __attribute__((visibility("hidden"))) int bkcore_internal_forward_sav
     float *save_r, float *save_s, const int *row_filter, const int *gate);
 
 // Launches of the ratio-form forward (bkcore_ratio.hip); errors are left for the caller's hipGetLastError().
+// mode 3: rows cut into S units of seg_ch chunks that hand over inside ONE launch; `save` then carries the number of
+// workgroups the GPU holds at once (the grid is at most that).
 // mode 0: one workgroup per row (save != 0: the variant that also stores r, s and writes G_raw); mode 1 / 2: per-segment
 // products / per-segment outputs of rows cut into S segments of seg_ch chunks, around bkcore_internal_ratio_combine.
 extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_ratio_forward(

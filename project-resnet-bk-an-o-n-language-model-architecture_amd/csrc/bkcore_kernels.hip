@@ -1342,14 +1342,14 @@ inline void relay_plan(int64_t B, int64_t N, int chunk, int wgs_per_cu, unsigned
   if (flags & BKCORE_FLAG_ROW_UNITS_MANY) forced = nch / 2;
   else if (flags & BKCORE_FLAG_ROW_UNITS) forced = 2;
   int want = forced >= 0 ? forced : 2;
-  // Worth it from the first row that does not fit the GPU at once up to about three rounds of rows: beyond that the
-  // last round is a small part of the launch and the extra workgroup starts cost more than it loses (measured at
-  // 8192 rows: 1.18 ms whole rows, 1.22 ms in units).
+  // Worth it from the first row that does not fit the GPU at once up to two rounds of rows: beyond that the last
+  // round is a small part of the launch and the hand-overs cost more than it loses (measured: 769 rows -6 %, 1024
+  // rows -5 %, 2000 rows +5 %, 8192 rows +3 %).
   // Nor when the last round is full or nearly so (16-bit operands run two workgroups per CU: 1024 rows are exactly
   // two rounds of 512).
   const int64_t places = (int64_t)wgs_per_cu * device_cu_count();
   const int64_t last = B % places;
-  if (want < 2 || nch < 4 || (forced < 0 && (B <= places || B >= 3 * places || last == 0 || 4 * last > 3 * places)))
+  if (want < 2 || nch < 4 || (forced < 0 && (B <= places || B >= 2 * places || last == 0 || 4 * last > 3 * places)))
     return;
   if (want > nch / 2) want = nch / 2;  // at least two chunks per unit
   seg_ch = (nch + want - 1) / want;
@@ -1426,7 +1426,7 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
     if (!SAVE && N <= BKCORE_INTERNAL_LONG_ROW && !(flags & BKCORE_FLAG_ADAPTIVE))
       relay_plan(B, N, bkcore_internal_ratio_chunk(), sizeof(TIn) == 2 ? 2 : 3, flags, RS, rseg);
     if (RS > 1)
-      fwd(dtype_tag<TIn>(), PHI_EXACT, 3, 0, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
+      fwd(dtype_tag<TIn>(), PHI_EXACT, 3, (sizeof(TIn) == 2 ? 2 : 3) * device_cu_count(), a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
           flags, fclamp, RS, rseg, nullptr, nullptr, stream);
     else
       fwd(dtype_tag<TIn>(), PHI_EXACT, 0, SAVE, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,

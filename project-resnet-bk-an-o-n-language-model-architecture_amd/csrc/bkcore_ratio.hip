@@ -93,6 +93,9 @@ static_assert(RT % 64 == 0 && RT >= 64 && RT <= 256, "whole waves, at most the s
 #ifndef BK_UNIT_STAMPS
 #define BK_UNIT_STAMPS 0      // development: per workgroup start / end wall clock and hardware id, 32 bytes each, 8 MiB
 #endif                        // into the lane-state region of the workspace (tools/dev_units.py)
+#ifndef BK_RELAY_PERSIST
+#define BK_RELAY_PERSIST 1    // MODE 3: one workgroup per place on the GPU, each taking every gridDim-th unit
+#endif
 #ifndef BK_RELAY_NOWAIT
 #define BK_RELAY_NOWAIT 0     // development: no hand-off at all (wrong results; the cost of everything else)
 #endif
@@ -450,16 +453,24 @@ __global__ __launch_bounds__(RT, ((MODE == 0 || MODE == 3) && !SAVE && !LONG && 
     int seg_ch, float2 *__restrict__ save_r_ = nullptr, float2 *__restrict__ save_s_ = nullptr) {
   __shared__ SharedR sh;
   constexpr bool RELAY = MODE == 3;
+  constexpr bool PERSIST = RELAY && BK_RELAY_PERSIST;
+  const unsigned units = RELAY ? (unsigned)B * (unsigned)S : 0u;
+  for (unsigned unit = blockIdx.x;;) {  // the units of this workgroup (a single pass unless PERSIST)
   long row = MODE == 0 ? (long)blockIdx.x : (long)(blockIdx.x / S);
   int sg = MODE == 0 ? 0 : (int)(blockIdx.x % S);
   if (RELAY) {
-    // Units in workgroup order, the rightmost segments of all rows first: the unit a workgroup depends on (same row,
-    // the segment to the right) has an index lower by B.  The hardware starts workgroups in index order, so that unit
-    // is running or done, and rightmost segments wait for nothing: the lowest unfinished unit can always proceed.
-    // (Should a wait outlast RELAY_WAIT_TICKS all the same, the unit gives up and the second launch recomputes
-    // every row.)
-    row = (long)(blockIdx.x % (unsigned)B);
-    sg = S - 1 - (int)(blockIdx.x / (unsigned)B);
+    // Units in index order, the rightmost segments of all rows first: the unit a workgroup depends on (same row, the
+    // segment to the right) has an index lower by B, and rightmost segments wait for nothing.  The grid is at most one
+    // workgroup per place on the GPU (PERSIST), workgroup w taking units w, w + gridDim, w + 2 gridDim, ... in that
+    // order: no counter to draw from (an atomic with a return value at every unit boundary measured 0.22 ms against
+    // 0.16), no workgroup turnover inside the launch.  The lowest unfinished unit belongs to a workgroup that has
+    // finished everything before it, and what it waits for is lower still, hence done: it can always proceed once
+    // its workgroup runs, and every workgroup of the grid gets to run because the grid fits the GPU (other work on
+    // the GPU delays that, it does not prevent it).  Without PERSIST: one workgroup per unit, started by the hardware
+    // in index order.  (Should a wait outlast RELAY_WAIT_TICKS all the same -- fewer places than the host assumed --
+    // the unit gives up and the second launch recomputes every row.)
+    row = (long)(unit % (unsigned)B);
+    sg = S - 1 - (int)(unit / (unsigned)B);
   }
   int *rowflag = reinterpret_cast<int *>(ws);
   if (MODE == 2 && rowflag[row] != 0) return;  // the whole row is recomputed by the scan kernel
@@ -839,7 +850,7 @@ __global__ __launch_bounds__(RT, ((MODE == 0 || MODE == 3) && !SAVE && !LONG && 
   for (int i = (int)((blockIdx.x * 2654435761u) >> 28); i > 0; --i) __builtin_amdgcn_s_sleep(BK_RATIO_STAGGER);
 #endif
 #if BK_UNIT_STAMPS
-  unsigned long long *ustamp = reinterpret_cast<unsigned long long *>(ws + rowflag_bytes(B) + (8u << 20)) + 4 * (size_t)blockIdx.x;
+  unsigned long long *ustamp = reinterpret_cast<unsigned long long *>(ws + rowflag_bytes(B) + (8u << 20)) + 4 * (size_t)(RELAY ? unit : blockIdx.x);
   if (threadIdx.x == 0) {
     ustamp[0] = wall_clock64();
     ustamp[2] = ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | (unsigned)__builtin_amdgcn_s_getreg(0xF804);
@@ -876,8 +887,8 @@ __global__ __launch_bounds__(RT, ((MODE == 0 || MODE == 3) && !SAVE && !LONG && 
     } else if (RELAY) {
       // (which unit this is, worked out again rather than kept in scalar registers across the chunk loop: the kernel
       // has none to spare)
-      const long row = (long)(blockIdx.x % (unsigned)B);
-      const int sg = S - 1 - (int)(blockIdx.x / (unsigned)B);
+      const long row = (long)(unit % (unsigned)B);
+      const int sg = S - 1 - (int)(unit / (unsigned)B);
       const int epoch = __hip_atomic_load(&state[ST_EPOCH], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       float *relay = reinterpret_cast<float *>(ws + rowflag_bytes(B)) + (row * S + sg) * RELAY_REC;
       // The row's verdict: the rightmost segment stores it before it publishes its record, the others have acquired
@@ -912,6 +923,10 @@ __global__ __launch_bounds__(RT, ((MODE == 0 || MODE == 3) && !SAVE && !LONG && 
     if (seen & 1u) __hip_atomic_store(&state[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (seen & 2u) __hip_atomic_store(&state[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (!PERSIST) break;
+  unit += gridDim.x;
+  if (unit >= units) break;
+  }  // units
 }
 
 // One wave per row, one lane per segment (64 at a time, right to left): the product entering each segment, the
@@ -984,7 +999,7 @@ void ratio_launch(int mode, int save, const void *a, long lda, const void *b, lo
   if (mode == 1) BK_RATIO(1, false, B * S);
   else if (mode == 2) BK_RATIO(2, false, B * S);
 #if !BK_RATIO_LONG
-  else if (mode == 3) BK_RATIO(3, false, B * S);
+  else if (mode == 3) BK_RATIO(3, false, (BK_RELAY_PERSIST && save > 0 && save < B * S) ? save : B * S);  // save: places
 #endif
   else if (!save) BK_RATIO(0, false, B);
 #if !BK_RATIO_LONG

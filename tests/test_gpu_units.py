@@ -202,7 +202,8 @@ def test_units_give_up_and_recover(bk):
     bk_core._DEBUG["row_units"] = 0
     assert 0.04 <= waited <= 5.0, waited
     st = bk_core._state_block(a.device, torch.cuda.current_stream().cuda_stream).tolist()
-    assert st[:9] == [0] * 9 and st[12] == 0
+    # (words 6-8 belong to the opt-in adaptive path and keep what earlier calls on this stream left there)
+    assert st[:6] == [0] * 6 and st[12] == 0
     ref = C.get_diag(a.cpu().numpy(), b.cpu().numpy(), c.cpu().numpy(), z)
     assert float(np.max(np.abs(G.cpu().numpy() - ref) / np.abs(ref))) <= 1e-4
     bk_core._DEBUG["scan_path"] = True          # every row from the scan kernels: what the recovery ran
