@@ -216,3 +216,21 @@ def test_units_give_up_and_recover(bk):
     (f0, G0, r0), (f1, G1, r1) = _both(bk, 16, a, b, c, z)  # and the units work again right after
     assert r0 == 0 and r1 == 0
     assert torch.equal(torch.view_as_real(G0), torch.view_as_real(G1))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_units_by_themselves_random_shapes(bk, seed):
+    """No flag: row counts between one and two rounds of workgroups, lengths of 4 to 9 chunks with ragged ends, any
+    operand type.  Rows in units against the same rows in a batch small enough to run as whole rows: bit for bit."""
+    from bkcore import bk_core
+    rng = np.random.RandomState(1000 + seed)
+    B = int(rng.randint(769, 1300))
+    N = int(rng.randint(4 * CH - 50, 9 * CH))
+    dtype = [torch.float32, torch.float32, torch.bfloat16, torch.float16][seed % 4]
+    a, b, c = _inputs(B, N, seed=2000 + seed, dtype=dtype, varying=bool(seed % 2))
+    z = complex(0.1 * seed, 0.8 + 0.1 * seed)
+    _, G = bk.bk_forward(a, b, c, z, want_features=False)
+    assert bk_core.rows_recomputed() == 0
+    rows = sorted(set(rng.randint(0, B, size=200).tolist()) | {0, B - 1})
+    _, Gs = bk.bk_forward(a[rows].contiguous(), b[rows].contiguous(), c[rows].contiguous(), z, want_features=False)
+    assert torch.equal(torch.view_as_real(Gs), torch.view_as_real(G[rows]))
