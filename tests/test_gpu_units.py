@@ -234,3 +234,29 @@ def test_units_by_themselves_random_shapes(bk, seed):
     rows = sorted(set(rng.randint(0, B, size=200).tolist()) | {0, B - 1})
     _, Gs = bk.bk_forward(a[rows].contiguous(), b[rows].contiguous(), c[rows].contiguous(), z, want_features=False)
     assert torch.equal(torch.view_as_real(Gs), torch.view_as_real(G[rows]))
+
+
+def test_units_repeatable_under_other_work(bk):
+    """The hand-over is timing dependent by nature (a workgroup polls for what another publishes): many calls, with
+    and without another stream keeping the GPU busy, must give the bits of the first call, and no wait may be given up."""
+    from bkcore import bk_core
+    bk_core._DEBUG["keep_ws"] = False
+    B, N = 1024, 8 * CH
+    a, b, c = _inputs(B, N, seed=21)
+    z = torch.tensor(1j, dtype=torch.complex64, device="cuda")
+    _, G0 = bk.bk_forward(a, b, c, z, want_features=False)
+    G0 = G0.clone()
+    side = torch.cuda.Stream()
+    x = torch.randn(64 << 20, device="cuda")
+    bad = 0
+    for it in range(120):
+        if it % 3 == 0:
+            with torch.cuda.stream(side):                 # competing memory traffic and workgroups
+                y = x * 1.0001 + 0.5
+                y2 = torch.cumsum(y[: 1 << 22], 0)
+        _, G = bk.bk_forward(a, b, c, z, want_features=False)
+        if it % 10 == 9:
+            bad += int(not torch.equal(torch.view_as_real(G), torch.view_as_real(G0)))
+    torch.cuda.synchronize()
+    st = bk_core._state_block(a.device, torch.cuda.current_stream().cuda_stream).tolist()
+    assert bad == 0 and st[12] == 0 and st[2] == 0
