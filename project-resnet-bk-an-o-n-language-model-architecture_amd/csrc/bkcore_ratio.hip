@@ -443,6 +443,9 @@ __device__ __forceinline__ unsigned commit_ratio(const RowCfg &cfg, const float 
 // Per-segment record (floats): [0,1] product mantissa, [2] exponent, [3] a check failed, [4..7] right edge
 // (theta end value, phi warm-up of the last lane), [8..11] left edge (theta warm-up, phi end value of the first lane),
 // [12,13] mantissa and [14] exponent of the product entering the segment.
+// MODE 3: more rows than the GPU holds workgroups at once: rows cut into S units of seg_ch chunks that hand the running
+// product and edge values on inside ONE launch (records and their tags: see RELAY_REC above); the same outputs as
+// MODE 0, bit for bit.
 // SAVE (MODE 0 only, for the analytic backward): also stores r_j and s_j, and writes G_raw (before the final
 // log-magnitude clamp and the clip; 0 outside 1e-18 <= |G_raw| <= 1e18) instead of G.
 template <typename TIn, bool PHI_EXACT, int MODE, bool SAVE = false>
