@@ -248,6 +248,21 @@ int bkcore_layer_epilogue_backward(const float *grad_out, const float *features,
 size_t bkcore_layer_epilogue_backward_workspace_bytes(int64_t n, int64_t D);
 
 /*
+ * The same two with the clamp of the features (`features = torch.clamp(features, -c, c)`,
+ * src/models/resnet_bk.py:216-217) applied as the features are read: `features` may then be the operator's unclamped
+ * output -- the float32 view of G_ii itself -- so that no clamped copy is ever written.  The backward's grad_features
+ * is the gradient with respect to the UNCLAMPED values (zero where |feature| > feature_clamp).  feature_clamp <= 0:
+ * no clamp (the plain entry points).
+ */
+int bkcore_layer_epilogue_clamped(const float *features, float feature_clamp, const float *weight, const float *bias,
+                                  const float *scale, const float *residual, int64_t n, int64_t D, float *out,
+                                  void *stream);
+int bkcore_layer_epilogue_backward_clamped(const float *grad_out, const float *features, float feature_clamp,
+                                           const float *weight, const float *bias, const float *scale, int64_t n,
+                                           int64_t D, float *grad_features, float *grad_weight, float *grad_bias,
+                                           float *grad_scale, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Cumulative sum along the middle dimension of a contiguous float32 tensor viewed as (outer, L, inner):
  * y[o, l, i] = sum_{l' <= l} x[o, l', i]  (reverse != 0: sum over l' >= l).  Replaces
  * fused_associative_scan(x, dim, reverse), src/kernels/associative_scan.py:211-308, and the torch.cumsum it falls back

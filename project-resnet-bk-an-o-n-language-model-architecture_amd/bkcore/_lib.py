@@ -18,14 +18,15 @@ FLAG_ROW_UNITS = 16
 FLAG_ROW_UNITS_MANY = 32
 FLAG_ROW_UNITS_MUTE = 64
 STATE_BYTES = 64
-ABI_VERSION = 14
+ABI_VERSION = 15
 EINVAL, ETOOLONG, ELAUNCH, EWORKSPACE, ETOOBIG = -1, -2, -3, -4, -5
 BWD_REFERENCE, BWD_BATCHED, BWD_SCAN_STABLE = 0, 1, 2
 NOALLOC_MAX_WORKSPACE = 8 << 20
 
 EXPORTS = ("bkcore_forward", "bkcore_forward_clamped", "bkcore_forward_noalloc", "bkcore_workspace_bytes", "bkcore_backward_ref", "bkcore_backward_ref_flagged", "bkcore_backward_variant", "bkcore_backward_analytic",
            "bkcore_backward_analytic_workspace_bytes", "bkcore_backward_analytic_rowflag_offset", "bkcore_layer_prologue", "bkcore_layer_backward_ref",
-           "bkcore_layer_epilogue", "bkcore_layer_epilogue_backward", "bkcore_layer_epilogue_backward_workspace_bytes", "bkcore_cumsum", "bkcore_woodbury_correct", "bkcore_woodbury_workspace_bytes",
+           "bkcore_layer_epilogue", "bkcore_layer_epilogue_backward", "bkcore_layer_epilogue_backward_workspace_bytes",
+           "bkcore_layer_epilogue_clamped", "bkcore_layer_epilogue_backward_clamped", "bkcore_cumsum", "bkcore_woodbury_correct", "bkcore_woodbury_workspace_bytes",
            "bkcore_max_seq_len", "bkcore_last_hip_error",
            "bkcore_error_string", "bkcore_abi_version")
 
@@ -74,6 +75,11 @@ def load():
     L.bkcore_layer_epilogue.restype = i32
     L.bkcore_layer_epilogue_backward.argtypes = [vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.bkcore_layer_epilogue_backward.restype = i32
+    L.bkcore_layer_epilogue_clamped.argtypes = [vp, f32, vp, vp, vp, vp, i64, i64, vp, vp]
+    L.bkcore_layer_epilogue_clamped.restype = i32
+    L.bkcore_layer_epilogue_backward_clamped.argtypes = [vp, vp, f32, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp,
+                                                         ctypes.c_size_t, vp]
+    L.bkcore_layer_epilogue_backward_clamped.restype = i32
     L.bkcore_layer_epilogue_backward_workspace_bytes.argtypes = [i64, i64]
     L.bkcore_layer_epilogue_backward_workspace_bytes.restype = ctypes.c_size_t
     L.bkcore_cumsum.argtypes = [vp, vp, i64, i64, i64, i32, vp]

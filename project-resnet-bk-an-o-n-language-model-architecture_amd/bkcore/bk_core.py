@@ -539,8 +539,9 @@ class FusedBKLayerFunction(torch.autograd.Function):
             b = b.expand(B, -1)
         if c.shape[0] != B:
             c = c.expand(B, -1)
+        # without a clamp the features are the float32 view of G: nothing more for the operator to write
         feats, G = bk_forward(he, b, c, z, raw=False, phi_exact=(BKCoreFunction.PHI_K_INDEX == "exact"),
-                              feature_clamp=feature_clamp)
+                              feature_clamp=feature_clamp, share_storage=feature_clamp is None)
         ctx.set_materialize_grads(False)
         ctx.bk_v_max = float(v_max)
         ctx.bk_clamp = feature_clamp
@@ -561,11 +562,15 @@ class FusedSpectralOutputFunction(torch.autograd.Function):
     """out = residual + bk_scale * output_proj(features) of the reference layer (src/models/resnet_bk.py:218-219) in
     one launch forward and one pass over the incoming gradient backward.
 
-        apply(features (..., 2) f32, weight (D, 2), bias (D,), bk_scale (D,), residual (..., D) f32 | None) -> (..., D) f32
-    """
+        apply(features (..., 2) f32, weight (D, 2), bias (D,), bk_scale (D,), residual (..., D) f32 | None
+              [, feature_clamp]) -> (..., D) f32
+
+    feature_clamp: the layer's ``torch.clamp(features, -c, c)`` (resnet_bk.py:216-217) is applied as the kernels read the
+    features, which then may be the operator's unclamped output (the float32 view of G_ii): no clamped copy is written,
+    and the gradient returned for ``features`` is the one with respect to the unclamped values."""
 
     @staticmethod
-    def forward(ctx, features, weight, bias, scale, residual):
+    def forward(ctx, features, weight, bias, scale, residual, feature_clamp=None):
         L = _lib.load()
         if not features.is_cuda:
             raise RuntimeError("bkcore: tensors must be on a ROCm device (no CPU path)")
@@ -584,14 +589,20 @@ class FusedSpectralOutputFunction(torch.autograd.Function):
                 raise ValueError(f"bkcore: residual must have shape {(*lead, D)}, got {tuple(residual.shape)}")
             res = residual.detach().float().contiguous()
         out = torch.empty((*lead, D), dtype=torch.float32, device=f.device)
+        fc = 0.0
+        if feature_clamp is not None:
+            fc = float(feature_clamp)
+            if not fc > 0.0:
+                raise ValueError("bkcore: feature_clamp must be positive")
         if n and D:
             with _on_device(f.device):
-                rc = L.bkcore_layer_epilogue(f.data_ptr(), w.data_ptr(), bb.data_ptr(), sc.data_ptr(),
-                                             res.data_ptr() if res is not None else None, n, D, out.data_ptr(),
-                                             torch.cuda.current_stream().cuda_stream)
+                rc = L.bkcore_layer_epilogue_clamped(f.data_ptr(), fc, w.data_ptr(), bb.data_ptr(), sc.data_ptr(),
+                                                     res.data_ptr() if res is not None else None, n, D,
+                                                     out.data_ptr(), torch.cuda.current_stream().cuda_stream)
             _lib.check(rc, "bkcore_layer_epilogue")
         ctx.save_for_backward(f, w, bb, sc)
         ctx.bk_has_res = residual is not None
+        ctx.bk_fc = fc
         return out
 
     @staticmethod
@@ -611,15 +622,16 @@ class FusedSpectralOutputFunction(torch.autograd.Function):
                 nbytes = int(L.bkcore_layer_epilogue_backward_workspace_bytes(n, D))
                 ws = torch.empty(nbytes, dtype=torch.uint8, device=f.device)
                 ptr = lambda t: t.data_ptr() if t is not None else None
-                rc = L.bkcore_layer_epilogue_backward(go.data_ptr(), f.data_ptr(), w.data_ptr(), bb.data_ptr(),
-                                                      sc.data_ptr(), n, D, gf.data_ptr(), ptr(gw), ptr(gb), ptr(gs),
-                                                      ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+                rc = L.bkcore_layer_epilogue_backward_clamped(go.data_ptr(), f.data_ptr(), ctx.bk_fc, w.data_ptr(),
+                                                              bb.data_ptr(), sc.data_ptr(), n, D, gf.data_ptr(),
+                                                              ptr(gw), ptr(gb), ptr(gs), ws.data_ptr(), nbytes,
+                                                              torch.cuda.current_stream().cuda_stream)
             _lib.check(rc, "bkcore_layer_epilogue_backward")
         else:
             for t in (gf, gw, gb, gs):
                 if t is not None:
                     t.zero_()
-        return (gf if ctx.needs_input_grad[0] else None, gw, gb, gs, go if ctx.bk_has_res else None)
+        return (gf if ctx.needs_input_grad[0] else None, gw, gb, gs, go if ctx.bk_has_res else None, None)
 
 
 def set_triton_mode(enabled: bool):

@@ -88,6 +88,20 @@ class BKCoreLayer(nn.Module):
     def forward(self, x: torch.Tensor, residual: torch.Tensor | None = None) -> torch.Tensor:
         """The layer's spectral branch: [residual +] bk_scale * output_proj(clamp(features)) (resnet_bk.py:216-219;
         ``residual`` is the reference's ``ffn_out``)."""
+        if self._use_fused() and self.d_model <= 1024:
+            # The clamped features never exist as a tensor: the operator writes G_ii alone, and the output stage reads
+            # its float32 view through the clamp (forward and backward).
+            B, N, _ = x.shape
+            if N != self.n_seq:
+                raise ValueError(f"Sequence length mismatch: expected {self.n_seq}, got {N}")
+            v = self.v_proj(x).squeeze(-1)
+            epsilon = F.softplus(self.epsilon_param) + 1e-4
+            z = (1.0j * epsilon + 1j * self.gamma).to(dtype=torch.complex64, device=v.device)
+            raw, g = FusedBKLayerFunction.apply(v, self.h0_diag_base, self.h0_super_base, self.h0_sub_base, z,
+                                                self.v_max, None)
+            self.last_g_ii = g.unsqueeze(-1)
+            return FusedSpectralOutputFunction.apply(raw, self.output_proj.weight, self.output_proj.bias,
+                                                     self.bk_scale, residual, self.feature_clamp)
         features, _ = self.spectral_features(x)
         if self._use_fused():                                          # clamped features; one launch for the rest
             if features.dtype == torch.float32 and self.d_model <= 1024:

@@ -1735,7 +1735,7 @@ int bkcore_layer_backward_ref(const float *G, const float *grad_features, const 
 int64_t bkcore_max_seq_len(void) { return (int64_t)MAX_N; }
 int bkcore_last_hip_error(void) { return g_last_hip_error; }
 void bkcore_internal_set_hip_error(int code) { g_last_hip_error = code; }
-int bkcore_abi_version(void) { return 14; }
+int bkcore_abi_version(void) { return 15; }
 
 const char *bkcore_error_string(int code) {
   switch (code) {

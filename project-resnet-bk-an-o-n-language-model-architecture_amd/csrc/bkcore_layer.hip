@@ -32,7 +32,7 @@ __global__ __launch_bounds__(LT) void bk_layer_epilogue_kernel(const float *__re
                                                                const float *__restrict__ bias,
                                                                const float *__restrict__ scale,
                                                                const float *__restrict__ res, long n, int D,
-                                                               float *__restrict__ out) {
+                                                               float fclamp, float *__restrict__ out) {
   constexpr int V = VEC ? 4 : 1;
   const int dv = D / V;  // vector slots per position
   const long total = n * (long)dv;
@@ -40,7 +40,9 @@ __global__ __launch_bounds__(LT) void bk_layer_epilogue_kernel(const float *__re
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
     const long i = idx / dv;
     const int d0 = (int)(idx - i * dv) * V;
-    const float f0 = feat[2 * i], f1 = feat[2 * i + 1];
+    // (fclamp = +inf: the features as they are)
+    const float f0 = __builtin_amdgcn_fmed3f(feat[2 * i], -fclamp, fclamp);
+    const float f1 = __builtin_amdgcn_fmed3f(feat[2 * i + 1], -fclamp, fclamp);
     float y[V];
 #pragma unroll
     for (int q = 0; q < V; ++q) {
@@ -68,7 +70,8 @@ __global__ __launch_bounds__(LT) void bk_layer_epilogue_bwd_kernel(const float *
                                                                    const float *__restrict__ feat,
                                                                    const float *__restrict__ W,
                                                                    const float *__restrict__ scale, long n, int D,
-                                                                   long rows_per_block, float *__restrict__ gfeat,
+                                                                   long rows_per_block, float fclamp,
+                                                                   float *__restrict__ gfeat,
                                                                    float *__restrict__ partials) {
   __shared__ float red[ROWS_TILE][LT / 64][2];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -89,7 +92,8 @@ __global__ __launch_bounds__(LT) void bk_layer_epilogue_bwd_kernel(const float *
       const long i = rt + rr;
       float p0 = 0.0f, p1 = 0.0f;
       if (i < r1) {  // uniform over the workgroup
-        const float f0 = feat[2 * i], f1 = feat[2 * i + 1];
+        const float f0 = __builtin_amdgcn_fmed3f(feat[2 * i], -fclamp, fclamp);
+        const float f1 = __builtin_amdgcn_fmed3f(feat[2 * i + 1], -fclamp, fclamp);
 #pragma unroll
         for (int q = 0; q < MAX_CPT; ++q) {
           const int d = t + q * LT;
@@ -117,7 +121,10 @@ __global__ __launch_bounds__(LT) void bk_layer_epilogue_bwd_kernel(const float *
     if (t < ROWS_TILE * 2) {
       const int rr = t >> 1, j = t & 1;
       const long i = rt + rr;
-      if (i < r1) gfeat[2 * i + j] = (red[rr][0][j] + red[rr][1][j]) + (red[rr][2][j] + red[rr][3][j]);
+      // the clamp passes the gradient on [-fclamp, fclamp] only
+      if (i < r1)
+        gfeat[2 * i + j] = fabsf(feat[2 * i + j]) <= fclamp
+                               ? (red[rr][0][j] + red[rr][1][j]) + (red[rr][2][j] + red[rr][3][j]) : 0.0f;
     }
     __syncthreads();
   }
@@ -155,7 +162,8 @@ __global__ __launch_bounds__(LT) void bk_layer_epilogue_bwd_wave_kernel(const fl
                                                                         const float *__restrict__ feat,
                                                                         const float *__restrict__ W,
                                                                         const float *__restrict__ scale, long n,
-                                                                        long rows_per_block, float *__restrict__ gfeat,
+                                                                        long rows_per_block, float fclamp,
+                                                                        float *__restrict__ gfeat,
                                                                         float *__restrict__ partials) {
   constexpr int D = 256 * Q;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -177,8 +185,10 @@ __global__ __launch_bounds__(LT) void bk_layer_epilogue_bwd_wave_kernel(const fl
   for (long i = r0 + wave; i < r1; i += 2 * WS) {
     const long i2 = i + WS;
     const bool two = i2 < r1;  // uniform over the wave
-    const float f0 = feat[2 * i], f1 = feat[2 * i + 1];
-    const float h0 = two ? feat[2 * i2] : 0.0f, h1 = two ? feat[2 * i2 + 1] : 0.0f;
+    const float r0f = feat[2 * i], r1f = feat[2 * i + 1];  // as stored; the sums take them clamped
+    const float t0f = two ? feat[2 * i2] : 0.0f, t1f = two ? feat[2 * i2 + 1] : 0.0f;
+    const float f0 = __builtin_amdgcn_fmed3f(r0f, -fclamp, fclamp), f1 = __builtin_amdgcn_fmed3f(r1f, -fclamp, fclamp);
+    const float h0 = __builtin_amdgcn_fmed3f(t0f, -fclamp, fclamp), h1 = __builtin_amdgcn_fmed3f(t1f, -fclamp, fclamp);
     const float4 *__restrict__ row = reinterpret_cast<const float4 *>(go + i * D) + lane;
     const float4 *__restrict__ row2 = reinterpret_cast<const float4 *>(go + (two ? i2 : i) * D) + lane;
     float4 g[Q], g2[Q];
@@ -217,9 +227,12 @@ __global__ __launch_bounds__(LT) void bk_layer_epilogue_bwd_wave_kernel(const fl
     p1 = wave_total_in_lane63(p1);
     q0 = wave_total_in_lane63(q0);
     q1 = wave_total_in_lane63(q1);
-    if (lane == 63) {
-      *reinterpret_cast<float2 *>(gfeat + 2 * i) = make_float2(p0, p1);
-      if (two) *reinterpret_cast<float2 *>(gfeat + 2 * i2) = make_float2(q0, q1);
+    if (lane == 63) {  // the clamp passes the gradient on [-fclamp, fclamp] only
+      *reinterpret_cast<float2 *>(gfeat + 2 * i) =
+          make_float2(fabsf(r0f) <= fclamp ? p0 : 0.0f, fabsf(r1f) <= fclamp ? p1 : 0.0f);
+      if (two)
+        *reinterpret_cast<float2 *>(gfeat + 2 * i2) =
+            make_float2(fabsf(t0f) <= fclamp ? q0 : 0.0f, fabsf(t1f) <= fclamp ? q1 : 0.0f);
     }
   }
   // the four waves' column sums are combined in LDS (fixed order) into one record per workgroup
@@ -294,6 +307,14 @@ extern "C" {
 
 int bkcore_layer_epilogue(const float *features, const float *weight, const float *bias, const float *scale,
                           const float *residual, int64_t n, int64_t D, float *out, void *stream) {
+  return bkcore_layer_epilogue_clamped(features, 0.0f, weight, bias, scale, residual, n, D, out, stream);
+}
+
+int bkcore_layer_epilogue_clamped(const float *features, float feature_clamp, const float *weight, const float *bias,
+                                  const float *scale, const float *residual, int64_t n, int64_t D, float *out,
+                                  void *stream) {
+  if (feature_clamp != feature_clamp) return BKCORE_EINVAL;
+  const float fclamp = feature_clamp > 0.0f ? feature_clamp : __builtin_huge_valf();
   if (n < 0 || D < 0 || D > 2147483647LL / 4) return BKCORE_EINVAL;
   if (n == 0 || D == 0) return BKCORE_OK;
   if (!features || !weight || !bias || !scale || !out) return BKCORE_EINVAL;
@@ -305,7 +326,7 @@ int bkcore_layer_epilogue(const float *features, const float *weight, const floa
   const dim3 grid((unsigned)blocks), block(LT);
 #define BK_EPI(VEC, RES)                                                                                              \
   hipLaunchKernelGGL((bk_layer_epilogue_kernel<VEC, RES>), grid, block, 0, s, features, weight, bias, scale, residual, \
-                     (long)n, (int)D, out)
+                     (long)n, (int)D, fclamp, out)
   if (vec && residual) BK_EPI(true, true);
   else if (vec) BK_EPI(true, false);
   else if (residual) BK_EPI(false, true);
@@ -323,6 +344,16 @@ int bkcore_layer_epilogue_backward(const float *grad_out, const float *features,
                                    const float *scale, int64_t n, int64_t D, float *grad_features, float *grad_weight,
                                    float *grad_bias, float *grad_scale, void *workspace, size_t workspace_bytes,
                                    void *stream) {
+  return bkcore_layer_epilogue_backward_clamped(grad_out, features, 0.0f, weight, bias, scale, n, D, grad_features,
+                                                grad_weight, grad_bias, grad_scale, workspace, workspace_bytes, stream);
+}
+
+int bkcore_layer_epilogue_backward_clamped(const float *grad_out, const float *features, float feature_clamp,
+                                           const float *weight, const float *bias, const float *scale, int64_t n,
+                                           int64_t D, float *grad_features, float *grad_weight, float *grad_bias,
+                                           float *grad_scale, void *workspace, size_t workspace_bytes, void *stream) {
+  if (feature_clamp != feature_clamp) return BKCORE_EINVAL;
+  const float fclamp = feature_clamp > 0.0f ? feature_clamp : __builtin_huge_valf();
   if (n < 0 || D < 0) return BKCORE_EINVAL;
   if (D > (int64_t)LT * MAX_CPT) return BKCORE_EINVAL;
   if (n == 0 || D == 0) return BKCORE_OK;
@@ -338,7 +369,7 @@ int bkcore_layer_epilogue_backward(const float *grad_out, const float *features,
   if (wave_rows) {
 #define BK_BWD_WAVE(Q)                                                                                              \
   hipLaunchKernelGGL((bk_layer_epilogue_bwd_wave_kernel<Q>), dim3((unsigned)nblk), dim3(LT), 0, s, grad_out, features, \
-                     weight, scale, (long)n, rows, grad_features, (float *)workspace)
+                     weight, scale, (long)n, rows, fclamp, grad_features, (float *)workspace)
     switch ((int)(D / 256)) {
       case 1: BK_BWD_WAVE(1); break;
       case 2: BK_BWD_WAVE(2); break;
@@ -348,7 +379,7 @@ int bkcore_layer_epilogue_backward(const float *grad_out, const float *features,
 #undef BK_BWD_WAVE
   } else {
     hipLaunchKernelGGL(bk_layer_epilogue_bwd_kernel, dim3((unsigned)nblk), dim3(LT), 0, s, grad_out, features, weight,
-                       scale, (long)n, (int)D, rows, grad_features, (float *)workspace);
+                       scale, (long)n, (int)D, rows, fclamp, grad_features, (float *)workspace);
   }
   if (grad_weight || grad_bias || grad_scale)
     hipLaunchKernelGGL(bk_layer_epilogue_bwd_finish_kernel, dim3((unsigned)((D + 31) / 32)), dim3(LT), 0, s,

@@ -231,3 +231,38 @@ def test_spectral_output_limits():
                                                  torch.ones(8, device="cuda"), None)
     with pytest.raises(RuntimeError, match="ROCm device"):
         bkcore.FusedSpectralOutputFunction.apply(torch.zeros(4, 2), torch.zeros(8, 2), torch.zeros(8), torch.ones(8), None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [256, 96])
+def test_output_stage_reads_features_through_the_clamp(D):
+    """FusedSpectralOutputFunction(raw, ..., feature_clamp=c) == the same function on torch.clamp(raw, -c, c)
+    (resnet_bk.py:216-219), bit for bit, and the gradient for `raw` is that of the clamp composed with it: zero where
+    |raw| > c (both the wave-per-position kernel, D = 256, and the general one)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import bkcore
+    g = torch.Generator().manual_seed(D)
+    n, c = 1500, 0.7
+    raw = torch.randn(n, 2, generator=g).cuda()
+    raw[3, 0] = c                      # on the boundary: the clamp's gradient is 1 there
+    raw[5, 1] = -c
+    lin = torch.nn.Linear(2, D).cuda()
+    sc = (1.0 + 0.1 * torch.randn(D, generator=g)).cuda().requires_grad_(True)
+    res = torch.randn(n, D, generator=g).cuda()
+    go = torch.randn(n, D, generator=g).cuda()
+
+    def run(through):
+        x = raw.detach().clone().requires_grad_(True)
+        lin.zero_grad(set_to_none=True); sc.grad = None
+        if through:
+            out = bkcore.FusedSpectralOutputFunction.apply(x, lin.weight, lin.bias, sc, res, c)
+        else:
+            out = bkcore.FusedSpectralOutputFunction.apply(torch.clamp(x, -c, c), lin.weight, lin.bias, sc, res)
+        out.backward(go)
+        return out.detach(), x.grad, lin.weight.grad.clone(), lin.bias.grad.clone(), sc.grad.clone()
+
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert float(a[1][raw.abs() > c].abs().max()) == 0.0 and float(a[1][3, 0].abs()) > 0.0

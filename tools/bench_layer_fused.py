@@ -85,3 +85,4 @@ for n_pos, D in ((8 * 256, 256), (64 * 2048, 256), (1024 * 1024, 256)):
     tu, tf = timed2(plain), timed2(fused_out)
     print(json.dumps({"output_stage_positions": n_pos, "D": D, "unfused_fwd_bwd_ms": tu, "fused_fwd_bwd_ms": tf,
                       "speedup": tu / tf}))
+
