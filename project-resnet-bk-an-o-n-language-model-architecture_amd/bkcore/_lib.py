@@ -27,7 +27,7 @@ EXPORTS = ("bkcore_forward", "bkcore_forward_clamped", "bkcore_forward_noalloc",
            "bkcore_backward_analytic_workspace_bytes", "bkcore_backward_analytic_rowflag_offset", "bkcore_layer_prologue", "bkcore_layer_backward_ref",
            "bkcore_layer_epilogue", "bkcore_layer_epilogue_backward", "bkcore_layer_epilogue_backward_workspace_bytes",
            "bkcore_layer_epilogue_clamped", "bkcore_layer_epilogue_backward_clamped", "bkcore_cumsum", "bkcore_woodbury_correct", "bkcore_woodbury_workspace_bytes",
-           "bkcore_max_seq_len", "bkcore_last_hip_error",
+           "bkcore_max_seq_len", "bkcore_forward_plan", "bkcore_last_hip_error",
            "bkcore_error_string", "bkcore_abi_version")
 
 _lib = None
@@ -89,6 +89,8 @@ def load():
     L.bkcore_woodbury_workspace_bytes.argtypes = [i64, i64, i64]
     L.bkcore_woodbury_workspace_bytes.restype = ctypes.c_size_t
     L.bkcore_max_seq_len.restype = i64
+    L.bkcore_forward_plan.argtypes = [i64, i64, i32, ctypes.c_uint, i32, ctypes.POINTER(ctypes.c_int)]
+    L.bkcore_forward_plan.restype = i32
     L.bkcore_last_hip_error.restype = i32
     L.bkcore_error_string.argtypes = [i32]
     L.bkcore_error_string.restype = ctypes.c_char_p

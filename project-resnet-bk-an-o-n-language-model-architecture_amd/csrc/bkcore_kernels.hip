@@ -1332,7 +1332,8 @@ inline int device_cu_count() {
   }
   return cus[dev];
 }
-inline void relay_plan(int64_t B, int64_t N, int chunk, int wgs_per_cu, unsigned flags, int &S, int &seg_ch) {
+inline void relay_plan(int64_t B, int64_t N, int chunk, int wgs_per_cu, unsigned flags, int &S, int &seg_ch,
+                       int cus = 0) {
   const int nch = (int)((N + chunk - 1) / chunk);
   S = 1;
   seg_ch = nch;
@@ -1347,7 +1348,7 @@ inline void relay_plan(int64_t B, int64_t N, int chunk, int wgs_per_cu, unsigned
   // rows -5 %, 2000 rows +5 %, 8192 rows +3 %).
   // Nor when the last round is full or nearly so (16-bit operands run two workgroups per CU: 1024 rows are exactly
   // two rounds of 512).
-  const int64_t places = (int64_t)wgs_per_cu * device_cu_count();
+  const int64_t places = (int64_t)wgs_per_cu * (cus > 0 ? cus : device_cu_count());
   const int64_t last = B % places;
   if (want < 2 || nch < 4 || (forced < 0 && (B <= places || B >= 2 * places || last == 0 || 4 * last > 3 * places)))
     return;
@@ -1733,6 +1734,22 @@ int bkcore_layer_backward_ref(const float *G, const float *grad_features, const 
 }
 
 int64_t bkcore_max_seq_len(void) { return (int64_t)MAX_N; }
+
+int bkcore_forward_plan(int64_t B, int64_t N, int in_dtype, unsigned flags, int cus, int *launches) {
+  if (launches) *launches = 0;
+  if (B <= 0 || N <= 0 || N > (int64_t)MAX_N || in_dtype < BKCORE_F32 || in_dtype > BKCORE_F64) return BKCORE_EINVAL;
+  int S = 1, seg_ch = 0;
+  split_plan(B, N, (flags & BKCORE_FLAG_SCAN_PATH) ? CHUNK : bkcore_internal_ratio_chunk(), S, seg_ch);
+  if (S > 1) {
+    if (launches) *launches = 4;
+    return S;
+  }
+  if (launches) *launches = 2;
+  if ((flags & (BKCORE_FLAG_SCAN_PATH | BKCORE_FLAG_ADAPTIVE)) || N > BKCORE_INTERNAL_LONG_ROW) return 1;
+  const bool half = in_dtype == BKCORE_BF16 || in_dtype == BKCORE_F16;
+  relay_plan(B, N, bkcore_internal_ratio_chunk(), half ? 2 : 3, flags, S, seg_ch, cus);
+  return S;
+}
 int bkcore_last_hip_error(void) { return g_last_hip_error; }
 void bkcore_internal_set_hip_error(int code) { g_last_hip_error = code; }
 int bkcore_abi_version(void) { return 15; }

@@ -92,3 +92,31 @@ def test_launch_failure_reports_the_hip_code_from_every_translation_unit():
         rc = call()
         assert rc == _lib.ELAUNCH, name
         assert L.bkcore_last_hip_error() != 0, name
+
+
+def test_forward_plan_policy():
+    """bkcore_forward_plan: which form of the forward a shape takes (pure host logic; a GPU with 256 CUs assumed).
+    Float32 operands hold 3 workgroups per CU, 16-bit operands 2."""
+    from bkcore import _lib
+    L = _lib.load()
+    n = ctypes.c_int(0)
+
+    def plan(B, N, dt=_lib.F32, flags=0):
+        s = L.bkcore_forward_plan(B, N, dt, flags, 256, ctypes.byref(n))
+        return s, n.value
+
+    assert plan(1024, 32768) == (2, 2)              # the headline shape: 1024 rows on 768 places, two pieces a row
+    assert plan(768, 32768) == (1, 2)               # one full round
+    assert plan(769, 32768) == (2, 2)
+    assert plan(1344, 32768) == (2, 2)              # last round three quarters full: still worth it
+    assert plan(1345, 32768) == (1, 2)
+    assert plan(1536, 32768) == (1, 2) and plan(2000, 32768) == (1, 2) and plan(8192, 32768) == (1, 2)
+    assert plan(1024, 3 * 4096) == (1, 2)           # fewer than four chunks: nothing to cut
+    assert plan(1024, 32768, _lib.BF16) == (1, 2)   # 512 places: exactly two rounds
+    assert plan(600, 32768, _lib.BF16) == (2, 2)
+    assert plan(1024, 32768, flags=_lib.FLAG_ADAPTIVE) == (1, 2)
+    assert plan(1024, 1 << 18) == (1, 2)            # rows beyond 131072 elements run in double, whole
+    s, l = plan(16, 1 << 20)                        # few long rows: several launches
+    assert s > 1 and l == 4
+    assert plan(100, 4 * 4096, flags=_lib.FLAG_ROW_UNITS) == (2, 2)
+    assert L.bkcore_forward_plan(0, 5, _lib.F32, 0, 256, None) == _lib.EINVAL
