@@ -439,7 +439,9 @@ int bkcore_woodbury_correct(const float *G, const float *U, const float *V, int6
   // The matrix-core forms work on tiles of 16 rows and 16 values of the rank index, 64 rows per workgroup: taken when
   // that gives the GPU enough workgroups (a few rows by a few thousand positions stay with the vector forms).
   const int64_t row_tiles = (B + MF_ROWS - 1) / MF_ROWS;
-  const bool mfma = r <= 16 && B >= 16 && row_tiles * mf_spans(N) >= 64 && !getenv("BKCORE_WOODBURY_NO_MFMA");
+  // (development: BKCORE_WOODBURY_NO_MFMA in the environment keeps the vector forms)
+  static const bool no_mfma = getenv("BKCORE_WOODBURY_NO_MFMA") != nullptr;
+  const bool mfma = r <= 16 && B >= 16 && row_tiles * mf_spans(N) >= 64 && !no_mfma;
   const int spans = mfma ? mf_spans(N) : gram_spans(N);
   const size_t rr = (size_t)(r * r);
   float2 *partial = (float2 *)workspace;
