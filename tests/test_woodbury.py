@@ -96,3 +96,28 @@ def test_woodbury_singular_row_is_left_uncorrected_and_limits():
     with pytest.raises(ValueError, match="rank"):
         bkcore.woodbury_correct(torch.zeros(1, 4, dtype=torch.complex64).cuda(), torch.zeros(4, 23).cuda(),
                                 torch.zeros(4, 23).cuda())
+
+
+@pytest.mark.gpu
+def test_woodbury_at_the_measured_shape():
+    """B = 1024, N = 32768, r = 15 (the shape of the measurements; matrix-core forms): a subset of rows against the
+    float64 loop -- rows are independent -- and run-to-run bitwise repeatability."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import bkcore
+    B, N, r = 1024, 32768, 15
+    g = torch.Generator(device="cuda").manual_seed(5)
+    G = 0.4 * torch.complex(torch.randn(B, N, generator=g, device="cuda"), torch.randn(B, N, generator=g, device="cuda"))
+    amp = 0.5 / N ** 0.25
+    U = amp * torch.randn(N, r, generator=g, device="cuda")
+    V = amp * torch.randn(N, r, generator=g, device="cuda")
+    out = bkcore.woodbury_correct(G, U, V)
+    out2 = bkcore.woodbury_correct(G, U, V)
+    assert torch.equal(torch.view_as_real(out), torch.view_as_real(out2))
+    rows = [0, 15, 16, 63, 64, 511, 1023]
+    want = _loop_f64(G[rows].cpu(), U.cpu(), V.cpu())
+    got = out[rows].cpu().to(torch.complex128)
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    # and the same rows as a batch too small for the matrix-core forms: the vector kernels agree to rounding
+    small = bkcore.woodbury_correct(G[rows[:3]].contiguous(), U, V).cpu().to(torch.complex128)
+    assert float((small - want[:3]).abs().max()) <= 1e-4 * float(want.abs().max())
