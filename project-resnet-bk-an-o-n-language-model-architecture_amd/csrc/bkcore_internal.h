@@ -43,6 +43,8 @@ extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_ratio_forw
 extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_ratio_combine_long(int64_t B, int64_t N, void *ws,
                                                                                         void *state, int S,
                                                                                         void *stream);
+// Workgroups of the mode 3 kernel one CU holds at once on the current device (0: unknown).
+extern "C" __attribute__((visibility("hidden"))) int bkcore_internal_ratio_unit_occupancy(int in_dtype, int phi_exact);
 // Elements per chunk of the ratio-form kernel (its workgroup size x 16).
 extern "C" __attribute__((visibility("hidden"))) int bkcore_internal_ratio_chunk(void);
 // Records the HIP error code that bkcore_last_hip_error() reports (per thread).

@@ -1424,10 +1424,13 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
     const auto fwd = (N > BKCORE_INTERNAL_LONG_ROW && !SAVE) ? bkcore_internal_ratio_forward_long
                                                              : bkcore_internal_ratio_forward;
     int RS = 1, rseg = 0;
-    if (!SAVE && N <= BKCORE_INTERNAL_LONG_ROW && !(flags & BKCORE_FLAG_ADAPTIVE))
-      relay_plan(B, N, bkcore_internal_ratio_chunk(), sizeof(TIn) == 2 ? 2 : 3, flags, RS, rseg);
+    // workgroups per CU: what the runtime says the kernel's registers and LDS allow on this device (the grid of the unit
+    // form must fit the GPU at once: its workgroups wait for each other); without an answer, whole rows
+    const int per_cu = (!SAVE && N <= BKCORE_INTERNAL_LONG_ROW && !(flags & BKCORE_FLAG_ADAPTIVE))
+                           ? bkcore_internal_ratio_unit_occupancy(dtype_tag<TIn>(), PHI_EXACT) : 0;
+    if (per_cu > 0) relay_plan(B, N, bkcore_internal_ratio_chunk(), per_cu, flags, RS, rseg);
     if (RS > 1)
-      fwd(dtype_tag<TIn>(), PHI_EXACT, 3, (sizeof(TIn) == 2 ? 2 : 3) * device_cu_count(), a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
+      fwd(dtype_tag<TIn>(), PHI_EXACT, 3, per_cu * device_cu_count(), a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
           flags, fclamp, RS, rseg, nullptr, nullptr, stream);
     else
       fwd(dtype_tag<TIn>(), PHI_EXACT, 0, SAVE, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,

@@ -1063,6 +1063,35 @@ extern "C" void BK_RATIO_ENTRY(bkcore_internal_ratio_forward)(int in_dtype, int 
 
 #if !BK_RATIO_LONG
 extern "C" int bkcore_internal_ratio_chunk(void) { return RCHUNK; }
+
+// Workgroups of the MODE 3 kernel that one CU holds at once on the current device, as the runtime computes it from the
+// kernel's registers and LDS (3 for float32 and float64 operands, 2 for 16-bit ones on the GPUs this was written for);
+// 0 if the query fails.  The grid of MODE 3 must not exceed CUs x this: its workgroups wait for each other.
+extern "C" int bkcore_internal_ratio_unit_occupancy(int in_dtype, int phi_exact) {
+  static int cache[4][2] = {};
+  if (in_dtype < 0 || in_dtype > 3) return 0;
+  int &slot = cache[in_dtype][phi_exact ? 1 : 0];
+  if (slot == 0) {
+    int n = 0;
+    hipError_t e = hipErrorInvalidValue;
+#define BK_OCC(TIN)                                                                                                   \
+  e = phi_exact ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bk_ratio_forward_kernel<TIN, true, 3, false>, RT, 0) \
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bk_ratio_forward_kernel<TIN, false, 3, false>, RT, 0)
+    switch (in_dtype) {
+      case BKCORE_F32: BK_OCC(float); break;
+#ifndef BK_DEV_F32_ONLY
+      case BKCORE_BF16: BK_OCC(uint16_t); break;
+      case BKCORE_F16: BK_OCC(_Float16); break;
+      case BKCORE_F64: BK_OCC(double); break;
+#endif
+      default: break;
+    }
+#undef BK_OCC
+    slot = (e == hipSuccess && n > 0) ? n : -1;
+    if (e != hipSuccess) (void)hipGetLastError();  // not an error of the caller's launch
+  }
+  return slot > 0 ? slot : 0;
+}
 #endif
 
 extern "C" void BK_RATIO_ENTRY(bkcore_internal_ratio_combine)(int64_t B, int64_t N, void *ws, void *state, int S,
