@@ -1,5 +1,7 @@
+"""Development: many calls of the forward in units with the hand-over statistics of a BK_RELAY_DEBUG build
+(bash tools/build_variant.sh dbg "-DBK_RELAY_DEBUG=1" first): waits per call, longest wait, give-ups, repeatability."""
 import os, sys, json, torch
-ROOT="/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "project-resnet-bk-an-o-n-language-model-architecture_amd"))
 from bkcore import _lib
 _lib.LIB_PATH = os.path.abspath(os.path.join(ROOT, "tools/ab/libbkcore_dbg.so"))

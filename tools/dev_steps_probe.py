@@ -1,5 +1,7 @@
+"""Development: per-step stream-event times of the benchmark's autograd step right after a process has started
+(kernel-only warm-up, five steps, then the timed ones): how long the host path takes to reach steady state."""
 import os, sys, time, torch
-ROOT="/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "project-resnet-bk-an-o-n-language-model-architecture_amd"))
 import bkcore
 from bkcore import BKCoreFunction
