@@ -9,6 +9,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--lib", default=None)
 ap.add_argument("--tag", default="lib")
 ap.add_argument("--iters", type=int, default=100)
+ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"])
+ap.add_argument("--rows", type=int, default=1024)
 args = ap.parse_args()
 from bkcore import _lib
 if args.lib:
@@ -28,20 +30,21 @@ def timed(fn, iters):
     ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
     return ts[len(ts) // 2], ts[0]
 
-out = {"tag": args.tag}
-B, N = 1024, 32768
+out = {"tag": args.tag, "dtype": args.dtype, "rows": args.rows}
+B, N = args.rows, 32768
+dt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
 g = torch.Generator(device="cuda").manual_seed(1234)
-a = -2.0 + 0.5 * torch.randn(B, N, device="cuda", generator=g)
-b = torch.ones(B, N - 1, device="cuda")
-c = torch.ones(B, N - 1, device="cuda")     # a buffer of its own: the kernel then reads 12 distinct bytes per element
+a = (-2.0 + 0.5 * torch.randn(B, N, device="cuda", generator=g)).to(dt)
+b = torch.ones(B, N - 1, device="cuda", dtype=dt)
+c = torch.ones(B, N - 1, device="cuda", dtype=dt)     # a buffer of its own: the kernel then reads 12 distinct bytes per element
 z = torch.tensor(1j, dtype=torch.complex64, device="cuda")
 gf = torch.randn(B, N, 2, device="cuda", generator=g)
 bk_core._DEBUG["keep_ws"] = True
 G = bkcore.bk_forward(a, b, c, z)[1]
 torch.cuda.synchronize()
 out["rows_recomputed"] = bk_core.rows_recomputed()
-rows = [0, 1, 511, 1023]
-ref = C.forward_f32(a[rows].cpu().numpy(), b[rows].cpu().numpy(), b[rows].cpu().numpy(), 1j)[1]
+rows = [0, 1, B // 2 - 1, B - 1]
+ref = C.forward_f32(a[rows].float().cpu().numpy(), b[rows].float().cpu().numpy(), b[rows].float().cpu().numpy(), 1j)[1]
 out["err_headline"] = float(np.max(np.abs(G[rows].cpu().numpy() - ref) / np.abs(ref)))
 # position-varying off-diagonals, general z
 g2 = torch.Generator().manual_seed(7)
