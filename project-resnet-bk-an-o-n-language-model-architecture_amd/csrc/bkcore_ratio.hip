@@ -99,6 +99,9 @@ static_assert(RT % 64 == 0 && RT >= 64 && RT <= 256, "whole waves, at most the s
 #ifndef BK_RELAY_NOWAIT
 #define BK_RELAY_NOWAIT 0     // development: no hand-off at all (wrong results; the cost of everything else)
 #endif
+#ifndef BK_COMMIT_SUMS
+#define BK_COMMIT_SUMS 1
+#endif
 #ifndef BK_RATIO_PREFETCH
 #define BK_RATIO_PREFETCH 1   // raw inputs of the next chunk held in registers during the current chunk's arithmetic
 #endif
@@ -374,9 +377,10 @@ __device__ __forceinline__ void load_ratio(const TIn *__restrict__ a, const TIn 
 static_assert(RT % E == 0, "padded slot arithmetic");
 constexpr int RQS = RT + RT / E;
 
-// EXACT: the operator's NaN rules element by element (bk_core.py:256-264), for a chunk in which some value is a NaN;
-// otherwise the clamps alone (v_med3).  The raw input registers are left as loaded.
-template <bool EXACT>
+// KIND 1: the operator's NaN rules element by element (bk_core.py:256-264), for a chunk in which some value is a NaN;
+// KIND 0: the clamps alone (v_med3); KIND 2: no clamps either (every value is known to lie inside them).  The raw input
+// registers are left as loaded.
+template <int KIND>
 __device__ __forceinline__ unsigned commit_pass(const RowCfg &cfg, const float (&av)[RNJ], const float (&bv)[RNJ],
                                                 const float (&cv)[RNJ], SharedR &sh) {
   unsigned seen = 0;
@@ -388,8 +392,8 @@ __device__ __forceinline__ unsigned commit_pass(const RowCfg &cfg, const float (
 #pragma unroll
   for (int j = 0; j < RNJ; ++j) {
     float a = av[j], b = bv[j], c = cv[j];
-    if (!cfg.raw) {
-      if (EXACT) {
+    if (KIND != 2 && !cfg.raw) {
+      if (KIND == 1) {
         a = clamp_keep_nan(a, 100.0f);
         if (a != a) { a = 0.0f; seen |= 1u; }
         b = clamp_keep_nan(b, 10.0f);
@@ -421,6 +425,22 @@ __device__ __forceinline__ unsigned commit_pass(const RowCfg &cfg, const float (
 
 __device__ __forceinline__ unsigned commit_ratio(const RowCfg &cfg, const float (&av)[RNJ], const float (&bv)[RNJ],
                                                  const float (&cv)[RNJ], SharedR &sh) {
+#if BK_COMMIT_SUMS
+  // Sums of squares (full-rate fma) instead of a clamp per value and a NaN test per pair (both half rate): a wave
+  // whose sums stay below the squares of the clamps' bounds holds no value outside them and no NaN, and its values go
+  // to LDS as they are.  Any other wave takes the passes below.
+  if (!cfg.raw) {
+    float sa = 0.0f, sb = 0.0f, sc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < RNJ; ++j) {
+      sa = fmaf(av[j], av[j], sa);
+      sb = fmaf(bv[j], bv[j], sb);
+      sc = fmaf(cv[j], cv[j], sc);
+    }
+    const bool plain = sa <= 1.0e4f && sb <= 1.0e2f && sc <= 1.0e2f;  // false for a NaN or an infinity
+    if (__builtin_expect(__all(plain), 1)) return commit_pass<2>(cfg, av, bv, cv, sh);
+  }
+#endif
   bool nan = false;  // v_cmp_u tests two values per instruction
   if (!cfg.raw) {
 #pragma unroll
@@ -430,8 +450,8 @@ __device__ __forceinline__ unsigned commit_ratio(const RowCfg &cfg, const float 
     }
     nan |= __builtin_isunordered(cv[RNJ - 1], cv[RNJ - 1]);
   }
-  unsigned seen = commit_pass<false>(cfg, av, bv, cv, sh);
-  if (__builtin_expect(__any(nan), 0)) seen = commit_pass<true>(cfg, av, bv, cv, sh);  // rewrites the wave's slots
+  unsigned seen = commit_pass<0>(cfg, av, bv, cv, sh);
+  if (__builtin_expect(__any(nan), 0)) seen = commit_pass<1>(cfg, av, bv, cv, sh);  // rewrites the wave's slots
   return seen;
 }
 

@@ -135,6 +135,46 @@ def test_small_and_ragged_lengths(bk, coracle, N):
     assert max_rel_err(G.cpu().numpy(), Gref) <= TOL
 
 
+@pytest.mark.parametrize("case", ["in_range_large_sums", "diag_outside", "offdiag_outside", "infinite_diag", "nan_diag"])
+def test_staging_shortcut_boundaries(bk, coracle, case):
+    """The staging step leaves the clamps out for a wave whose sums of squares prove every value inside them.  Values
+    inside the clamps whose sums are large, single values outside them, an infinity and a NaN must all still give the
+    operator's results (bk_core.py:249-264)."""
+    g = torch.Generator().manual_seed(len(case))
+    B, N = 3, 8192 + 100
+    a = -8.0 + 0.5 * torch.randn(B, N, generator=g)
+    b = 1.0 + 0.1 * torch.randn(B, N - 1, generator=g)
+    c = 1.0 + 0.1 * torch.randn(B, N - 1, generator=g)
+    if case == "in_range_large_sums":
+        a -= 22.0
+        b *= 3.0
+        c *= -3.0
+    elif case == "diag_outside":
+        a[1, 5000] = 250.0
+        a[2, 70] = -1.0e6
+        a[2, N - 1] = 101.0
+    elif case == "offdiag_outside":
+        b[0, 4100] = 25.0
+        c[1, 8000] = -40.0
+        b[2, 0] = 10.5
+    elif case == "infinite_diag":
+        a[0, 3000] = float("inf")
+        a[1, 3] = float("-inf")
+    elif case == "nan_diag":
+        a[0, 6000] = float("nan")
+    z = 0.3 + 0.9j
+    feats, G = bk.BKCoreFunction.apply(a.cuda(), b.cuda(), c.cuda(), z)
+    F, Gref = coracle.forward_f32(a.numpy(), b.numpy(), c.numpy(), z)
+    assert np.isfinite(Gref).all()
+    assert max_rel_err(G.cpu().numpy(), Gref) <= TOL
+    # the same rows in one batch with rows that take the shortcut: bit for bit the same results
+    a2 = torch.cat([a, -2.0 + 0.5 * torch.randn(2, N, generator=g)])
+    b2 = torch.cat([b, torch.ones(2, N - 1)])
+    c2 = torch.cat([c, torch.ones(2, N - 1)])
+    G2 = bk.BKCoreFunction.apply(a2.cuda(), b2.cuda(), c2.cuda(), z)[1]
+    assert torch.equal(G2[:B], G)
+
+
 def test_empty_inputs(bk):
     z = 1j
     feats, G = bk.BKCoreFunction.apply(torch.zeros(4, 0, device="cuda"), torch.zeros(4, 0, device="cuda"),
