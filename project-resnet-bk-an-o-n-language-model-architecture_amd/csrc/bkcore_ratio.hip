@@ -847,24 +847,31 @@ __global__ __launch_bounds__(RT, ((MODE == 0 || MODE == 3) && !SAVE && !LONG && 
     float2 *__restrict__ Fc = F ? F + base : nullptr;
     const int n_here = TAIL ? (int)max(0L, min((long)RCHUNK, N - base)) : RCHUNK;
     const bool clampf = cfg.fclamp <= 3.0e38f;  // uniform
+    // (the three cases as loops of their own: with the tests on Fc and clampf inside one loop the compiler kept a
+    // scalar branch, selects and a second address computation at every store)
+    auto store_tile = [&](auto with_f, auto clamped) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
-      const int idx = t + j * RT;
-      if (!TAIL || idx < n_here) {
-        const float2 gv = sh.u.out_s[(t + (t >> 4)) + j * (RT + RT / 16)];  // pad16(idx)
-        __builtin_nontemporal_store(gv.x, &Gc[idx].x);
-        __builtin_nontemporal_store(gv.y, &Gc[idx].y);
-        if (Fc) {
-          if (clampf) {
-            __builtin_nontemporal_store(__builtin_amdgcn_fmed3f(gv.x, -cfg.fclamp, cfg.fclamp), &Fc[idx].x);
-            __builtin_nontemporal_store(__builtin_amdgcn_fmed3f(gv.y, -cfg.fclamp, cfg.fclamp), &Fc[idx].y);
-          } else {
-            __builtin_nontemporal_store(gv.x, &Fc[idx].x);
-            __builtin_nontemporal_store(gv.y, &Fc[idx].y);
+      for (int j = 0; j < E; ++j) {
+        const int idx = t + j * RT;
+        if (!TAIL || idx < n_here) {
+          const float2 gv = sh.u.out_s[(t + (t >> 4)) + j * (RT + RT / 16)];  // pad16(idx)
+          __builtin_nontemporal_store(gv.x, &Gc[idx].x);
+          __builtin_nontemporal_store(gv.y, &Gc[idx].y);
+          if constexpr (decltype(with_f)::value) {
+            if constexpr (decltype(clamped)::value) {
+              __builtin_nontemporal_store(__builtin_amdgcn_fmed3f(gv.x, -cfg.fclamp, cfg.fclamp), &Fc[idx].x);
+              __builtin_nontemporal_store(__builtin_amdgcn_fmed3f(gv.y, -cfg.fclamp, cfg.fclamp), &Fc[idx].y);
+            } else {
+              __builtin_nontemporal_store(gv.x, &Fc[idx].x);
+              __builtin_nontemporal_store(gv.y, &Fc[idx].y);
+            }
           }
         }
       }
-    }
+    };
+    if (!Fc) store_tile(BoolC<false>{}, BoolC<false>{});
+    else if (clampf) store_tile(BoolC<true>{}, BoolC<true>{});
+    else store_tile(BoolC<true>{}, BoolC<false>{});
     BK_STAMP(11);
   };
 #if BK_RATIO_STAMPS

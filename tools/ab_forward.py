@@ -11,6 +11,7 @@ ap.add_argument("--tag", default="lib")
 ap.add_argument("--iters", type=int, default=100)
 ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"])
 ap.add_argument("--rows", type=int, default=1024)
+ap.add_argument("--n", type=int, default=32768)
 args = ap.parse_args()
 from bkcore import _lib
 if args.lib:
@@ -30,8 +31,8 @@ def timed(fn, iters):
     ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
     return ts[len(ts) // 2], ts[0]
 
-out = {"tag": args.tag, "dtype": args.dtype, "rows": args.rows}
-B, N = args.rows, 32768
+out = {"tag": args.tag, "dtype": args.dtype, "rows": args.rows, "n": args.n}
+B, N = args.rows, args.n
 dt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
 g = torch.Generator(device="cuda").manual_seed(1234)
 a = (-2.0 + 0.5 * torch.randn(B, N, device="cuda", generator=g)).to(dt)
