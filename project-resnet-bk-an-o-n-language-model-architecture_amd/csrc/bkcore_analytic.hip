@@ -643,18 +643,25 @@ __device__ __forceinline__ void issue_chunk(const float *__restrict__ a, const f
 // lanes' output pass the raw diagonal, b and c of the chunk's own elements.
 __device__ __forceinline__ void commit_chunk(const Raw &R, const float *__restrict__ gG, long base, long N, float2 z,
                                              SharedSweep &sh, int t) {
+  // Padded slot of q = t + j T is q + q / EB = (t + t / EB) + j (T + T / EB): one per-thread index plus compile-time
+  // offsets (the compiler does not split the division by itself), and the slots of the chunk's own elements e = q - WH
+  // and off-diagonal entries e - 1 are fixed distances from it.
+  static_assert(T % EB == 0 && WH % EB == 0 && WH + 1 < T && CHUNK == (ROUNDS - 1) * T, "slot arithmetic");
+  constexpr int PT = T + T / EB;
+  const int st = t + t / EB;                           // slot of q (j = 0)
+  const int sa = st - (WH + WH / EB);                  // slot of e = q - WH
+  const int sb = t + (t + EB - 1) / EB - (WH + 1) - (WH / EB + 1);  // slot of e - 1 = q - WH - 1
 #pragma unroll
   for (int j = 0; j < ROUNDS; ++j) {
     const int q = t + j * T;
     if (j < ROUNDS - 1 || q < SN) {
-      sh.k_s[q + q / EB] = R.bv[j] * R.cv[j];
-      sh.al_s[q + q / EB] = reg_diag(R.av[j], z);
-      const int e = q - WH;
+      sh.k_s[st + j * PT] = R.bv[j] * R.cv[j];
+      sh.al_s[st + j * PT] = reg_diag(R.av[j], z);
 #if BK_SWEEP_LDS_ABC
-      if (e >= 0 && e < CHUNK) sh.a_s[e + e / EB] = R.av[j];
-      if (e >= 1 && e <= CHUNK) sh.bc_s[(e - 1) + (e - 1) / EB] = make_float2(R.bv[j], R.cv[j]);
-#else
-      (void)e;
+      // e = q - WH in [0, CHUNK): only the first round has slots before it, only the last one slots after it
+      if ((j > 0 || t >= WH) && (j < ROUNDS - 1 || t < WH)) sh.a_s[sa + j * PT] = R.av[j];
+      if ((j > 0 || t >= WH + 1) && (j < ROUNDS - 1 || t <= WH))  // e in [1, CHUNK]
+        sh.bc_s[sb + j * PT] = make_float2(R.bv[j], R.cv[j]);
 #endif
     }
   }
@@ -666,7 +673,7 @@ __device__ __forceinline__ void commit_chunk(const Raw &R, const float *__restri
     // a cotangent that is not a number counts as 0, as in the reference's backward (bk_core.py:321-325)
     const float gx = fabsf(g.x) <= 3.0e38f ? g.x : 0.0f;
     const float gy = fabsf(g.y) <= 3.0e38f ? g.y : 0.0f;
-    sh.q_s[e + e / EB] = cot_q_saved(R.Gv[r], make_float2(gx, gy));
+    sh.q_s[st + r * PT] = cot_q_saved(R.Gv[r], make_float2(gx, gy));
   }
 }
 
