@@ -2,7 +2,11 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "project-resnet-bk-an-o-n-language-model-architecture_amd"))
-import torch, bkcore
+import torch
+if os.environ.get('BK_LIB'):
+    from bkcore import _lib
+    _lib.LIB_PATH = os.path.abspath(os.environ['BK_LIB'])
+import bkcore
 B, N = int(os.environ.get("BK_B", 1024)), int(os.environ.get("BK_N", 32768))
 g = torch.Generator(device="cuda").manual_seed(1234)
 a = -2.0 + 0.5 * torch.randn(B, N, generator=g, device="cuda")
