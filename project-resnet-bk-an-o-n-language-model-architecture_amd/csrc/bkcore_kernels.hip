@@ -1201,21 +1201,37 @@ __global__ __launch_bounds__(256) void bk_layer_prologue_kernel(const float *__r
   for (long row = blockIdx.y; row < B; row += gridDim.y) {
     const float *__restrict__ v = v_pre + row * ldv;
     if (VEC) {
-      for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < N / 4; q += (long)gridDim.x * blockDim.x) {
-        const float4 vv = reinterpret_cast<const float4 *>(v)[q];
-        const float4 hh = reinterpret_cast<const float4 *>(h0_diag)[q];
-        float4 he;
-        he.x = hh.x + saturate_potential(vv.x, v_max, inv_v_max);
-        he.y = hh.y + saturate_potential(vv.y, v_max, inv_v_max);
-        he.z = hh.z + saturate_potential(vv.z, v_max, inv_v_max);
-        he.w = hh.w + saturate_potential(vv.w, v_max, inv_v_max);
-        if (OUT_BF16) {
-          uint2 pk;
-          pk.x = (unsigned)to_bf16_rne(he.x) | ((unsigned)to_bf16_rne(he.y) << 16);
-          pk.y = (unsigned)to_bf16_rne(he.z) | ((unsigned)to_bf16_rne(he.w) << 16);
-          reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(he_diag) + row * N)[q] = pk;
-        } else {
-          reinterpret_cast<float4 *>(reinterpret_cast<float *>(he_diag) + row * N)[q] = he;
+      // PQ quads per thread and pass, a workgroup's threads side by side within each: all loads of a pass are issued
+      // before the first tanh (one quad per thread left two loads in flight per thread and the kernel waiting on them)
+      constexpr int PQ = 4;
+      const long nq = N / 4;
+      for (long q0 = (long)blockIdx.x * (blockDim.x * PQ) + threadIdx.x; q0 < nq; q0 += (long)gridDim.x * blockDim.x * PQ) {
+        float4 vv[PQ], hh[PQ];
+#pragma unroll
+        for (int k = 0; k < PQ; ++k) {
+          const long q = q0 + (long)k * blockDim.x;
+          if (q < nq) {
+            vv[k] = reinterpret_cast<const float4 *>(v)[q];
+            hh[k] = reinterpret_cast<const float4 *>(h0_diag)[q];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < PQ; ++k) {
+          const long q = q0 + (long)k * blockDim.x;
+          if (q >= nq) break;
+          float4 he;
+          he.x = hh[k].x + saturate_potential(vv[k].x, v_max, inv_v_max);
+          he.y = hh[k].y + saturate_potential(vv[k].y, v_max, inv_v_max);
+          he.z = hh[k].z + saturate_potential(vv[k].z, v_max, inv_v_max);
+          he.w = hh[k].w + saturate_potential(vv[k].w, v_max, inv_v_max);
+          if (OUT_BF16) {
+            uint2 pk;
+            pk.x = (unsigned)to_bf16_rne(he.x) | ((unsigned)to_bf16_rne(he.y) << 16);
+            pk.y = (unsigned)to_bf16_rne(he.z) | ((unsigned)to_bf16_rne(he.w) << 16);
+            reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(he_diag) + row * N)[q] = pk;
+          } else {
+            reinterpret_cast<float4 *>(reinterpret_cast<float *>(he_diag) + row * N)[q] = he;
+          }
         }
       }
     } else {
@@ -1682,12 +1698,12 @@ int bkcore_layer_prologue(const float *v_pre, int64_t ldv, const float *h0_diag,
   if (B == 0 || N == 0) return BKCORE_OK;
   if (!v_pre || !h0_diag || !he_diag) return BKCORE_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  long gx = (N + 1023) / 1024;
+  const bool vec = (N % 4) == 0 && (ldv % 4) == 0 && ((uintptr_t)v_pre % 16) == 0 && ((uintptr_t)h0_diag % 16) == 0 &&
+                   ((uintptr_t)he_diag % 16) == 0;
+  long gx = vec ? (N + 4095) / 4096 : (N + 1023) / 1024;  // vectorised: 4 quads per thread and pass
   if (gx > 1024) gx = 1024;
   const dim3 grid((unsigned)gx, (unsigned)(B > 32768 ? 32768 : B)), block(256);
   const float inv = 1.0f / v_max;
-  const bool vec = (N % 4) == 0 && (ldv % 4) == 0 && ((uintptr_t)v_pre % 16) == 0 && ((uintptr_t)h0_diag % 16) == 0 &&
-                   ((uintptr_t)he_diag % 16) == 0;
 #define BK_PRO(BF, VEC)                                                                                              \
   hipLaunchKernelGGL((bk_layer_prologue_kernel<BF, VEC>), grid, block, 0, s, v_pre, (long)ldv, h0_diag, v_max, inv,  \
                      (long)B, (long)N, he_diag)

@@ -17,7 +17,7 @@ def _unfused_he_diag(v_pre, h0_diag, v_max):
     return (h0_diag.reshape(1, -1).expand(v.shape[0], -1) + v).to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("B,N", [(1, 1), (3, 17), (8, 256), (5, 4097), (64, 1024)])
+@pytest.mark.parametrize("B,N", [(1, 1), (3, 17), (8, 256), (5, 4097), (64, 1024), (2, 5296), (3, 20000), (2, 32768)])
 def test_prologue_matches_tensor_ops(B, N):
     _need_gpu()
     import bkcore
