@@ -3,7 +3,11 @@ usage: prof_woodbury.py [B N r]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "project-resnet-bk-an-o-n-language-model-architecture_amd"))
-import torch, bkcore
+import torch
+if os.environ.get('BKCORE_DEV_LIB'):
+    from bkcore import _lib
+    _lib.LIB_PATH = os.path.abspath(os.environ['BKCORE_DEV_LIB'])
+import bkcore
 B, N, r = (int(x) for x in sys.argv[1:4]) if len(sys.argv) >= 4 else (1024, 32768, 15)
 g = torch.Generator(device="cuda").manual_seed(0)
 G = 0.4 * torch.complex(torch.randn(B, N, generator=g, device="cuda"), torch.randn(B, N, generator=g, device="cuda"))
