@@ -3,6 +3,9 @@ import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "project-resnet-bk-an-o-n-language-model-architecture_amd"))
+if os.environ.get('BKCORE_DEV_LIB'):
+    from bkcore import _lib
+    _lib.LIB_PATH = os.path.abspath(os.environ['BKCORE_DEV_LIB'])
 import bkcore
 
 def t_fwd(B, N, reps=10):
