@@ -288,12 +288,15 @@ size_t bkcore_woodbury_workspace_bytes(int64_t B, int64_t N, int64_t r);
 /* Largest N bkcore_forward accepts. */
 int64_t bkcore_max_seq_len(void);
 
-/* Diagnostics: how bkcore_forward would run a (B, N) problem of operand type in_dtype with `flags` and a state block, on
- * a GPU with `cus` compute units (<= 0: the current device's, 256 if there is none).  Returns pieces per row: 1 = one
- * workgroup per row; > 1 = rows cut into that many pieces, *launches saying how: 2 = the ratio-form launch plus the
- * (normally empty) launch for rows to recompute, pieces handing over inside the first (more rows than the GPU holds
- * workgroups at once); 4 = few long rows, piece products / combination / piece outputs / the launch for rows to
- * recompute.  No counterpart in the reference. */
+/* Diagnostics: how bkcore_forward would run a (B, N) problem of operand type in_dtype with `flags` and a state block.
+ * cus <= 0: on the current device, with the workgroups per compute unit its runtime reports for the kernel (whole rows
+ * if there is no device or no answer: exactly what the dispatch does); cus > 0: what-if for a GPU with that many
+ * compute units holding 3 workgroups each (2 for 16-bit operands).  Returns pieces per row: 1 = one workgroup per row;
+ * > 1 = rows cut into that many pieces that hand the running product over inside the first launch -- halves of rows
+ * when there are more rows than the GPU holds workgroups at once, single chunks when there are few long rows.
+ * *launches: 2 = that launch plus the (normally empty) launch for rows to recompute; 4 = few long rows in scan form
+ * (BKCORE_FLAG_SCAN_PATH): piece aggregates / combination / piece outputs / rows to recompute.  No counterpart in the
+ * reference. */
 int bkcore_forward_plan(int64_t B, int64_t N, int in_dtype, unsigned flags, int cus, int *launches);
 /* HIP error code of the last failed launch on this thread (0 if none). */
 int bkcore_last_hip_error(void);

@@ -10,8 +10,8 @@ a list of small seeded cases:
 
   * ``G``  = vmapped_get_diag(a, b, c, z)                      (bk_core.py:214-216)
   * ``features, G`` = BKCoreFunction.apply(a, b, c, z, False, False)   (sequential path, bk_core.py:239-300)
-  * ``grad_he_diag`` from BKCoreFunction.backward for GRAD_BLEND in {0, 0.5, 1},
-    with and without a cotangent on the complex output               (bk_core.py:303-385)
+  * ``grad_he_diag`` from BKCoreFunction.backward for GRAD_BLEND in {0, 0.5, 1}, with a cotangent on the
+    features only, on both outputs, and on the complex output only   (bk_core.py:303-385)
   * true autograd gradients (a, b, c) through vmapped_get_diag in float64  ("analytic" mode oracle)
   * the dense-inverse diagonal for small N (what tests/test_bk_core.py:47-77 compares with)
 
@@ -136,14 +136,18 @@ def main():
         out[f"{name}/gG"] = gG.numpy()
         for alpha in (0.0, 0.5, 1.0):
             BKCoreFunction.GRAD_BLEND = alpha
-            for with_gG in (False, True):
+            # cotangent on the features only / on both outputs / on G_ii only (the features unused: what the hybrid
+            # attention layer of configs/phase7_small.yaml does with the operator, resnet_bk.py:172-185)
+            for tag in ("gG0", "gG1", "gGonly"):
                 ar = a.clone().requires_grad_(True)
                 feats, G = BKCoreFunction.apply(ar, b, c, z, False, False)
-                loss = (feats * gf).sum()
-                if with_gG:
+                loss = 0.0
+                if tag != "gGonly":
+                    loss = loss + (feats * gf).sum()
+                if tag != "gG0":
                     loss = loss + (G.real * gG.real + G.imag * gG.imag).sum()
                 loss.backward()
-                out[f"{name}/grad_ref_a{alpha}_gG{int(with_gG)}"] = ar.grad.numpy()
+                out[f"{name}/grad_ref_a{alpha}_{tag}"] = ar.grad.numpy()
         BKCoreFunction.GRAD_BLEND = 0.5
         out[f"{name}/features"] = feats.detach().numpy()
         out[f"{name}/G"] = G.detach().numpy()

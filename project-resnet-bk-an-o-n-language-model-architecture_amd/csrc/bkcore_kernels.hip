@@ -605,10 +605,29 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
     const int sc = __hip_atomic_load(&state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // state[12]: a hand-off inside the first launch was given up (rows cut into units of one launch): every row again
     const int sd = __hip_atomic_load(&state[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // second == 2: the first launch cut rows into units that hand over inside the launch and tag their records with
-    // the epoch in state[9]; the next launch needs a new one
-    if (second == 2 && blockIdx.x == 0 && threadIdx.x == 0)
-      __hip_atomic_fetch_add(&state[9], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // second & 3 == 2 / 3: the first launch cut rows into units / chunks that hand over inside the launch (second >> 2
+    // records per row) and tag their records with the epoch in state[9].  The next launch needs a new epoch, and every
+    // tag of this one comes down here: a record whose reader gave up, or one whose epoch repeats because the state
+    // block was zeroed again (the memset of a replayed graph), must not pass for a hand-over of a later call.
+    if ((second & 3) >= 2) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&state[9], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&state[10], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the chunk counter of mode 4
+      }
+      const int per_row = second >> 2;
+      float *recs = reinterpret_cast<float *>(ws + rowflag_bytes(B));
+      if ((second & 3) == 2) {
+        for (int i = 1 + (int)threadIdx.x; i < per_row; i += T)
+          __hip_atomic_store(reinterpret_cast<unsigned long long *>(recs + (row * per_row + i) * 16 + 8), 0ull,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        for (int i = (int)threadIdx.x; i < per_row; i += T) {
+          float *rec = recs + (row * per_row + i) * 32;
+          __hip_atomic_store(reinterpret_cast<unsigned long long *>(rec + 12), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(reinterpret_cast<unsigned long long *>(rec + 28), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
     if (!(sa | sb | sc | sd)) return;  // nothing was flagged by the first launch: the usual case
     fix_bc = (sa != 0 && sb != 0) && !(flags & BKCORE_FLAG_RAW);
     const bool redo_row = sd != 0 || (sc != 0 && rowflag[row] != 0);
@@ -1394,9 +1413,26 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
   int S = 1, seg_ch = 0;
   if (state && !SAVE)
     split_plan(B, N, (flags & BKCORE_FLAG_SCAN_PATH) ? CHUNK : bkcore_internal_ratio_chunk(), S, seg_ch);
-  if (S > 1 && !(flags & BKCORE_FLAG_SCAN_PATH)) {
-    // few long rows, ratio form: segment products, combine, segment outputs, then the (normally empty) launch of
-    // the scan kernel for rows whose checks failed
+  static const int legacy_split = [] { const char *e = getenv("BKCORE_SPLIT_LEGACY"); return e ? atoi(e) : 0; }();
+  if (S > 1 && !(flags & BKCORE_FLAG_SCAN_PATH) && !legacy_split) {
+    // few long rows, ratio form: one workgroup per chunk, the running product handed from chunk to chunk inside the
+    // launch; then the (normally empty) launch of the scan kernel for rows whose checks failed
+    const auto fwd = N > BKCORE_INTERNAL_LONG_ROW ? bkcore_internal_ratio_forward_long : bkcore_internal_ratio_forward;
+    const int nch = (int)((N + bkcore_internal_ratio_chunk() - 1) / bkcore_internal_ratio_chunk());
+    fwd(dtype_tag<TIn>(), PHI_EXACT, 4, 0, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
+        flags, fclamp, nch, 1, nullptr, nullptr, stream);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess) {
+      BK_LAUNCH(false, 3 | (nch << 2));
+      err = hipGetLastError();
+    }
+    if (err != hipSuccess) {
+      g_last_hip_error = (int)err;
+      return BKCORE_ELAUNCH;
+    }
+  } else if (S > 1 && !(flags & BKCORE_FLAG_SCAN_PATH)) {
+    // (development: BKCORE_SPLIT_LEGACY=1) segment products, combine, segment outputs, then the (normally empty)
+    // launch of the scan kernel for rows whose checks failed
     // rows beyond BKCORE_INTERNAL_LONG_ROW elements: chains and product in double
     const auto fwd = N > BKCORE_INTERNAL_LONG_ROW ? bkcore_internal_ratio_forward_long : bkcore_internal_ratio_forward;
     const auto comb = N > BKCORE_INTERNAL_LONG_ROW ? bkcore_internal_ratio_combine_long : bkcore_internal_ratio_combine;
@@ -1453,7 +1489,7 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
           flags, fclamp, 1, 0, save_r, save_s, stream);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) {
-      if (RS > 1) BK_LAUNCH(false, 2);
+      if (RS > 1) BK_LAUNCH(false, 2 | (RS << 2));
       else BK_LAUNCH(false, 1);
       err = hipGetLastError();
     }
@@ -1760,13 +1796,28 @@ int bkcore_forward_plan(int64_t B, int64_t N, int in_dtype, unsigned flags, int 
   int S = 1, seg_ch = 0;
   split_plan(B, N, (flags & BKCORE_FLAG_SCAN_PATH) ? CHUNK : bkcore_internal_ratio_chunk(), S, seg_ch);
   if (S > 1) {
-    if (launches) *launches = 4;
-    return S;
+    if (flags & BKCORE_FLAG_SCAN_PATH) {
+      if (launches) *launches = 4;
+      return S;
+    }
+    if (launches) *launches = 2;
+    return (int)((N + bkcore_internal_ratio_chunk() - 1) / bkcore_internal_ratio_chunk());  // one workgroup per chunk
   }
   if (launches) *launches = 2;
   if ((flags & (BKCORE_FLAG_SCAN_PATH | BKCORE_FLAG_ADAPTIVE)) || N > BKCORE_INTERNAL_LONG_ROW) return 1;
-  const bool half = in_dtype == BKCORE_BF16 || in_dtype == BKCORE_F16;
-  relay_plan(B, N, bkcore_internal_ratio_chunk(), half ? 2 : 3, flags, S, seg_ch, cus);
+  int per_cu;
+  if (cus > 0) {
+    per_cu = (in_dtype == BKCORE_BF16 || in_dtype == BKCORE_F16) ? 2 : 3;
+  } else {
+    int ndev = 0;  // as the dispatch: what the runtime reports for this kernel on the current device, whole rows without
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+      (void)hipGetLastError();
+      return 1;
+    }
+    per_cu = bkcore_internal_ratio_unit_occupancy(in_dtype, (flags & BKCORE_FLAG_PHI_EXACT) != 0);
+    if (per_cu <= 0) return 1;
+  }
+  relay_plan(B, N, bkcore_internal_ratio_chunk(), per_cu, flags, S, seg_ch, cus);
   return S;
 }
 int bkcore_last_hip_error(void) { return g_last_hip_error; }

@@ -99,6 +99,15 @@ static_assert(RT % 64 == 0 && RT >= 64 && RT <= 256, "whole waves, at most the s
 #ifndef BK_RELAY_NOWAIT
 #define BK_RELAY_NOWAIT 0     // development: no hand-off at all (wrong results; the cost of everything else)
 #endif
+#ifndef BK_LOOK_TICKET
+#define BK_LOOK_TICKET 0      // MODE 4: a workgroup draws its chunk from a counter in the state block when it starts
+#endif                        // (0: the chunk is the workgroup's index, relying on workgroups starting in index order)
+#ifndef BK_LOOK_LONG3
+#define BK_LOOK_LONG3 0       // MODE 4 with double chains: three workgroups per CU (register budget 168)
+#endif
+#ifndef BK_LOOK_NOWAIT
+#define BK_LOOK_NOWAIT 0      // development: the chunks of MODE 4 do not wait for each other (wrong results; timing only)
+#endif
 #ifndef BK_COMMIT_SUMS
 #define BK_COMMIT_SUMS 1
 #endif
@@ -201,12 +210,51 @@ struct SharedR {
 // memory left in the record cannot pass for a hand-off (a foreign value would have to equal a 64-bit hash of the
 // current epoch), and the reader of a record takes its tag down, so neither can what an earlier launch left.
 constexpr int RELAY_REC = 16;
-constexpr int ST_EPOCH = 9, ST_REDO_ALL = 12;  // ints of the state block used by MODE 3
+constexpr int ST_EPOCH = 9, ST_TICKET = 10, ST_REDO_ALL = 12;  // ints of the state block used by MODE 3 and 4
 constexpr long long RELAY_WAIT_TICKS = 5000000;  // of the 100 MHz wall clock: 50 ms before a unit gives the launch up
 __device__ __forceinline__ unsigned long long relay_tag(int epoch, long unit) {
   unsigned long long x = ((unsigned long long)(unsigned)epoch << 32) ^ (unsigned long long)unit ^ 0x9E3779B97F4A7C15ull;
   x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 29; x *= 0x94D049BB133111EBull; x ^= x >> 32;
   return x | 1ull;
+}
+
+// MODE 4 hand-over between the chunks of one row, all in ONE launch (few long rows): one workgroup per chunk, started
+// in the order "rightmost chunks of all rows first", so that what a chunk waits for always has a lower index.  The
+// chains of a chunk do not depend on the running product, only its epilogue does: a chunk publishes its own product
+// (its "aggregate", with the edge values of its leftmost lane) as soon as its chains and the workgroup scan are done,
+// and one wave then collects the product of everything to its right from its neighbours' records.  So that the
+// result does not depend on who finished when, WHICH records are combined is fixed: every LB_W-th chunk (an anchor)
+// also publishes the running product up to and including itself, and a chunk reads the anchor to its right plus
+// every aggregate between that anchor and itself -- at most LB_W records, one per lane, multiplied in a fixed tree.
+// Record of LB_REC floats per (row, chunk) in the lane-state region of the workspace: [0..3] aggregate mantissa (two
+// floats, or two doubles in the long-row build), [4] its exponent, [8..11] edge values, [12,13] tag of the aggregate,
+// [16..19] running product mantissa, [20] exponent, [28,29] its tag.  Tags as for MODE 3 (hash of the call's epoch and
+// the record's index); the call's last launch takes every tag down again.
+constexpr int LB_REC = 32;
+constexpr int LB_W = 64;
+constexpr int LB_A_EXP = 4, LB_EDGE = 8, LB_A_TAG = 12, LB_P = 16, LB_P_EXP = 20, LB_P_TAG = 28;
+static_assert(LB_W == 64, "one record per lane of the collecting wave");
+__device__ __forceinline__ void lb_put(float *rec, int at, int ate, const Prod &p) {
+  if (LONG) {
+    __hip_atomic_store(reinterpret_cast<double *>(rec + at), (double)p.m.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<double *>(rec + at) + 1, (double)p.m.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    __hip_atomic_store(rec + at, (float)p.m.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(rec + at + 1, (float)p.m.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __hip_atomic_store(reinterpret_cast<int *>(rec + ate), p.e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ Prod lb_get(const float *rec, int at, int ate) {
+  Prod p;
+  if (LONG) {
+    p.m = c2((Real)__hip_atomic_load(reinterpret_cast<const double *>(rec + at), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+             (Real)__hip_atomic_load(reinterpret_cast<const double *>(rec + at) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  } else {
+    p.m = c2((Real)__hip_atomic_load(rec + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+             (Real)__hip_atomic_load(rec + at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
+  p.e = __hip_atomic_load(reinterpret_cast<const int *>(rec + ate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return p;
 }
 
 __device__ __forceinline__ int rpad16(int q) { return q + q / E; }  // lane stride E + 1 entries
@@ -469,13 +517,14 @@ __device__ __forceinline__ unsigned commit_ratio(const RowCfg &cfg, const float 
 // SAVE (MODE 0 only, for the analytic backward): also stores r_j and s_j, and writes G_raw (before the final
 // log-magnitude clamp and the clip; 0 outside 1e-18 <= |G_raw| <= 1e18) instead of G.
 template <typename TIn, bool PHI_EXACT, int MODE, bool SAVE = false>
-__global__ __launch_bounds__(RT, ((MODE == 0 || MODE == 3) && !SAVE && !LONG && sizeof(TIn) != 2) ? BK_RATIO_WAVES : 2) void bk_ratio_forward_kernel(
+__global__ __launch_bounds__(RT, (MODE == 4 && (!LONG || BK_LOOK_LONG3)) ? BK_RATIO_WAVES : ((MODE == 0 || MODE == 3) && !SAVE && !LONG && sizeof(TIn) != 2) ? BK_RATIO_WAVES : 2) void bk_ratio_forward_kernel(
     const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
     const float *__restrict__ z_dev, float z_re, float z_im, long B, long N_, float2 *__restrict__ G_,
     float2 *__restrict__ F_, char *__restrict__ ws, int *state, unsigned flags, float fclamp, int S,
     int seg_ch, float2 *__restrict__ save_r_ = nullptr, float2 *__restrict__ save_s_ = nullptr) {
   __shared__ SharedR sh;
   constexpr bool RELAY = MODE == 3;
+  constexpr bool LOOK = MODE == 4;   // one workgroup per chunk; S = chunks per row, sg = the chunk counted from the right
   constexpr bool PERSIST = RELAY && BK_RELAY_PERSIST;
   const unsigned units = RELAY ? (unsigned)B * (unsigned)S : 0u;
   // PERSIST, two units a row, at most half as many rows again as workgroups ("paired"): workgroup w does its own row
@@ -487,6 +536,20 @@ __global__ __launch_bounds__(RT, ((MODE == 0 || MODE == 3) && !SAVE && !LONG && 
   for (unsigned unit = (paired && blockIdx.x < (unsigned)B - gridDim.x) ? gridDim.x + blockIdx.x : blockIdx.x;;) {
   long row = MODE == 0 ? (long)blockIdx.x : (long)(blockIdx.x / S);
   int sg = MODE == 0 ? 0 : (int)(blockIdx.x % S);
+  if (LOOK) {  // rightmost chunks of all rows first: what a chunk waits for has a lower index
+    unsigned u = blockIdx.x;
+#if BK_LOOK_TICKET
+    // the index comes from a counter, drawn when the workgroup starts: every lower index then belongs to a workgroup
+    // that has started already, whatever order the hardware starts workgroups in
+    __shared__ unsigned ticket_s;
+    if (threadIdx.x == 0)
+      ticket_s = (unsigned)__hip_atomic_fetch_add(&state[ST_TICKET], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    u = ticket_s;
+#endif
+    row = (long)(u % (unsigned)B);
+    sg = (int)(u / (unsigned)B);
+  }
   if (RELAY) {
     // Units in index order, the rightmost segments of all rows first: the unit a workgroup depends on (same row, the
     // segment to the right) has an index lower by B, and rightmost segments wait for nothing.  The grid is at most one
@@ -515,8 +578,8 @@ __global__ __launch_bounds__(RT, ((MODE == 0 || MODE == 3) && !SAVE && !LONG && 
   float2 *G = G_ + row * N_ + shift;
   float2 *F = F_ ? F_ + row * N_ + shift : nullptr;
   const int nch = (int)((N + RCHUNK - 1) / RCHUNK);
-  const int ch0 = (MODE == 0 || RELAY) ? 0 : sg * seg_ch;
-  const int ch1 = MODE == 0 ? nch : min(nch, ch0 + seg_ch);
+  const int ch0 = (MODE == 0 || RELAY) ? 0 : LOOK ? nch - 1 - sg : sg * seg_ch;
+  const int ch1 = MODE == 0 ? nch : LOOK ? ch0 + 1 : min(nch, ch0 + seg_ch);
   float *info = reinterpret_cast<float *>(ws + rowflag_bytes(B) + lane_state_bytes(B, N_)) + (row * S + sg) * SEG_INFO;
   RowCfg cfg;
   cfg.z = z_dev ? make_float2(z_dev[0], z_dev[1]) : make_float2(z_re, z_im);
@@ -548,7 +611,7 @@ __global__ __launch_bounds__(RT, ((MODE == 0 || MODE == 3) && !SAVE && !LONG && 
   // (2 waves per SIMD).
   // 16-bit operands (the layer's bfloat16 diagonal) measured faster with two workgroups per CU and the prefetch:
   // twice the load instructions per byte
-  constexpr bool PREFETCH = !((MODE == 0 || MODE == 3) && !SAVE && BK_RATIO_WAVES >= 3 && sizeof(TIn) != 2) && !LONG && BK_RATIO_PREFETCH;
+  constexpr bool PREFETCH = !((MODE == 0 || MODE == 3) && !SAVE && BK_RATIO_WAVES >= 3 && sizeof(TIn) != 2) && !LONG && !LOOK && BK_RATIO_PREFETCH;
   float av[RNJ], bv[RNJ], cv[RNJ];
   auto prefetch = [&](int ch) __attribute__((always_inline)) {
     // `full`: the chunk and its halos (and the one extra k) lie inside the row
@@ -757,6 +820,98 @@ __global__ __launch_bounds__(RT, ((MODE == 0 || MODE == 3) && !SAVE && !LONG && 
                                    dpp_f<DPP_WAVE_SHR1, 0xF>(0.f, ph_fin.x), dpp_f<DPP_WAVE_SHR1, 0xF>(0.f, ph_fin.y));
     __syncthreads();
     BK_STAMP(7);
+    if constexpr (LOOK) {
+      if (wave == 0) {
+        // the chunk's own product and the edge values of its leftmost lane go out first: chunks to the left wait for them
+        Prod total = sh.tot[buf][0];
+#pragma unroll
+        for (int wv = 1; wv < RWAVES; ++wv) total = pmul(total, sh.tot[buf][wv]);
+        float *recs = reinterpret_cast<float *>(ws + rowflag_bytes(B)) + row * (long)nch * LB_REC;
+        float *me = recs + (long)sg * LB_REC;
+        const int epoch = __hip_atomic_load(&state[ST_EPOCH], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long uid0 = (row * (long)nch) << 1;
+        if (lane == 0) {
+          // the row's verdict starts at zero with its rightmost chunk; the others add to it after they have seen a
+          // record that was published after this store
+          if (sg == 0) __hip_atomic_store(&rowflag[row], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!(flags & BKCORE_FLAG_ROW_UNITS_MUTE)) {
+            const float4 ed = sh.wedge[buf][RWAVES - 1];
+            lb_put(me, 0, LB_A_EXP, total);
+            __hip_atomic_store(me + LB_EDGE + 0, ed.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(me + LB_EDGE + 1, ed.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(me + LB_EDGE + 2, ed.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(me + LB_EDGE + 3, ed.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record (and the verdict's start) before its tag
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(me + LB_A_TAG), relay_tag(epoch, uid0 + 2 * sg),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        Prod entering = prod_one();
+        float4 edge_in = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool failed = false;
+        if (sg > 0) {
+          const int q = (sg / LB_W) * LB_W - 1;           // the anchor to the right (-1: none, the row ends first)
+          const int nA = sg - 1 - q;                       // aggregates between it and this chunk: 0 .. LB_W - 1
+          const bool isA = lane < nA;
+          const bool isP = lane == LB_W - 1 && q >= 0;
+          const bool mine = isA || isP || lane == 0;       // lane 0 also fetches the right neighbour's edge values
+          const int pos = isP ? q : sg - 1 - (mine ? lane : 0);
+          const float *src = recs + (long)pos * LB_REC;
+          const unsigned long long want = relay_tag(epoch, uid0 + 2 * pos + (isP ? 1 : 0));
+          const unsigned long long *tagp = reinterpret_cast<const unsigned long long *>(src + (isP ? LB_P_TAG : LB_A_TAG));
+          bool got = !mine || BK_LOOK_NOWAIT;
+          const long long t0 = wall_clock64();
+#pragma unroll 1
+          for (;;) {
+            if (!got) got = __hip_atomic_load(tagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
+            if (__all(got)) break;
+            // never expected (every record waited for belongs to a workgroup that started earlier); once one chunk
+            // has given up nobody waits any more and the second launch recomputes every row
+            if (__any(wall_clock64() - t0 > RELAY_WAIT_TICKS ||
+                      __hip_atomic_load(&state[ST_REDO_ALL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+              failed = true;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // records are read only after their tags have been seen
+          if (failed) {
+            if (lane == 0) __hip_atomic_store(&state[ST_REDO_ALL], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            Prod w = prod_one();
+            if (isA) w = lb_get(src, 0, LB_A_EXP);
+            else if (isP) w = lb_get(src, LB_P, LB_P_EXP);
+            if (lane == 0)
+              edge_in = make_float4(__hip_atomic_load(src + LB_EDGE + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                    __hip_atomic_load(src + LB_EDGE + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                    __hip_atomic_load(src + LB_EDGE + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                    __hip_atomic_load(src + LB_EDGE + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            // the product of the wave's 64 values, always in the same tree
+            w = pmul(w, prod_dpp<DPP_ROW_SHR1, 0xF>(w));
+            w = pmul(w, prod_dpp<DPP_ROW_SHR2, 0xF>(w));
+            w = pmul(w, prod_dpp<DPP_ROW_SHR4, 0xF>(w));
+            w = pmul(w, prod_dpp<DPP_ROW_SHR8, 0xF>(w));
+            w = pmul(w, prod_dpp<DPP_ROW_BCAST15, 0xA>(w));
+            w = pmul(w, prod_dpp<DPP_ROW_BCAST31, 0xC>(w));
+            entering.m.x = __shfl(w.m.x, 63);
+            entering.m.y = __shfl(w.m.y, 63);
+            entering.e = __shfl(w.e, 63);
+          }
+        }
+        if (lane == 0) {
+          sh.carry[buf] = entering;
+          sh.edge[buf ^ 1] = edge_in;
+          if (!failed && (sg % LB_W) == LB_W - 1 && sg < nch - 1 && !(flags & BKCORE_FLAG_ROW_UNITS_MUTE)) {
+            // an anchor: the running product up to and including this chunk
+            lb_put(me, LB_P, LB_P_EXP, pmul(entering, total));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(me + LB_P_TAG), relay_tag(epoch, uid0 + 2 * sg + 1),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+      __syncthreads();
+    }
     Prod v = sh.carry[buf];
     Prod fin_in = v;
 #pragma unroll
@@ -772,7 +927,7 @@ __global__ __launch_bounds__(RT, ((MODE == 0 || MODE == 3) && !SAVE && !LONG && 
     {
       float4 nb = nbv;  // thread t-1's (theta warm-up, phi end) inside the wave
       if (lane == 0) nb = wave > 0 ? sh.wedge[buf][wave - 1] : sh.edge[buf ^ 1];
-      if (t > 0 || ch < (RELAY ? nch : ch1) - 1) {
+      if (t > 0 || ch < ((RELAY || LOOK) ? nch : ch1) - 1) {
         bad |= differs_tight(make_float2(nb.x, nb.y), th_fin);
         bad |= differs_tight(ph_west, make_float2(nb.z, nb.w));
       }
@@ -947,6 +1102,11 @@ __global__ __launch_bounds__(RT, ((MODE == 0 || MODE == 3) && !SAVE && !LONG && 
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       // (the epoch moves on in the call's last launch, which every MODE 3 launch is followed by)
+    } else if (LOOK) {
+      if (any_bad) {
+        __hip_atomic_fetch_or(&rowflag[row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&state[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     } else if (MODE == 1) {
       put_prod(info, 0, 16, 2, sh.carry[nscan & 1]);  // started from one: the segment's own product
       info[3] = any_bad ? 1.0f : 0.0f;
@@ -1042,6 +1202,7 @@ void ratio_launch(int mode, int save, const void *a, long lda, const void *b, lo
                      (float2 *)save_r, (float2 *)save_s)
   if (mode == 1) BK_RATIO(1, false, B * S);
   else if (mode == 2) BK_RATIO(2, false, B * S);
+  else if (mode == 4) BK_RATIO(4, false, B * S);
 #if !BK_RATIO_LONG
   else if (mode == 3) BK_RATIO(3, false, (BK_RELAY_PERSIST && save > 0 && save < B * S) ? save : B * S);  // save: places
 #endif
@@ -1095,9 +1256,14 @@ extern "C" int bkcore_internal_ratio_chunk(void) { return RCHUNK; }
 // kernel's registers and LDS (3 for float32 and float64 operands, 2 for 16-bit ones on the GPUs this was written for);
 // 0 if the query fails.  The grid of MODE 3 must not exceed CUs x this: its workgroups wait for each other.
 extern "C" int bkcore_internal_ratio_unit_occupancy(int in_dtype, int phi_exact) {
-  static int cache[4][2] = {};
+  static int cache[64][4][2] = {};  // per device: GPUs of one process need not be alike
+  int dev = 0;
   if (in_dtype < 0 || in_dtype > 3) return 0;
-  int &slot = cache[in_dtype][phi_exact ? 1 : 0];
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  int &slot = cache[dev][in_dtype][phi_exact ? 1 : 0];
   if (slot == 0) {
     int n = 0;
     hipError_t e = hipErrorInvalidValue;

@@ -116,7 +116,8 @@ def test_forward_plan_policy():
     assert plan(600, 32768, _lib.BF16) == (2, 2)
     assert plan(1024, 32768, flags=_lib.FLAG_ADAPTIVE) == (1, 2)
     assert plan(1024, 1 << 18) == (1, 2)            # rows beyond 131072 elements run in double, whole
-    s, l = plan(16, 1 << 20)                        # few long rows: several launches
-    assert s > 1 and l == 4
+    assert plan(16, 1 << 20) == (256, 2)            # few long rows: one workgroup per chunk, handing over in the launch
+    s, l = plan(16, 1 << 20, flags=_lib.FLAG_SCAN_PATH)
+    assert s > 1 and l == 4                         # scan form: aggregates / combination / outputs / rows to recompute
     assert plan(100, 4 * 4096, flags=_lib.FLAG_ROW_UNITS) == (2, 2)
     assert L.bkcore_forward_plan(0, 5, _lib.F32, 0, 256, None) == _lib.EINVAL

@@ -99,7 +99,9 @@ def test_autograd_function_end_to_end(bk, golden):
         ref = cs[f"grad_ref_a{alpha}_gG0"]
         got = a.grad.cpu().numpy()
         # the reference gradient has terms ~1/G^2, so a 1e-5 relative difference in G moves it by ~2e-5
-        assert np.max(np.abs(got - ref) / (np.abs(ref) + 1e-3 * np.abs(ref).max())) <= 2e-4
+        err = float(np.max(np.abs(got - ref) / (np.abs(ref) + 1e-3 * np.abs(ref).max())))
+        print(f"alpha={alpha}: gradient error {err:.2e}")
+        assert err <= TOL
     bk.BKCoreFunction.GRAD_BLEND = 0.5
     assert a.grad.dtype == torch.float32 and a.grad.shape == a.shape
 
