@@ -11,6 +11,17 @@ forward signatures on top of the HIP operator.
                               recurrence in its own CUDA kernels and clamps Re/Im to +-10; here the numbers come from
                               the HIP operator (regularised, soft-clamped: the semantics of bk_core.py) followed by the
                               same +-10 clamp, so results agree to the regularisation's 1e-3 on well-conditioned input.
+  * ``HybridGatedMixing``     what the reference's ``HybridHyperbolicAttention`` does with the resolvent diagonal
+                              (src/models/phase7/hybrid_attention.py:84-86,110-147): soft caps of the two mixing
+                              paths, the gate ``g = sigmoid(clamp(|Im G_ii|, max=100) * gate_sensitivity)``,
+                              ``g * local + (1 - g) * global``, LayerNorm.  Same parameter names (``gate_sensitivity``,
+                              ``layer_norm``).  The mixing paths themselves (windowed hyperbolic attention, AR-SSM) are
+                              arguments: they are not part of this package.
+  * ``BKHybridLayer``         ``MoEResNetBKLayer`` with ``use_hybrid_attention=True`` (resnet_bk.py:137-202), the
+                              consumer configs/phase7_small.yaml:11 selects: the features are unused, ``G_ii`` feeds the
+                              gate, and the operator's backward receives a cotangent on ``G_ii`` only.  The two mixing
+                              paths are stand-ins (causal softmax attention in windows; a causal running mean over the
+                              sequence through the library's cumulative sum).
   * ``LearnedTridiagonalGreen`` the Green-function step of the reference's hyperbolic BK-Core block
                               (src/models/phase8/bk_core_hyperbolic.py:282-286, 349-407): all three diagonals are
                               projections of the input (``he_diag_proj``, ``h0_super_proj``, ``h0_sub_proj``, same names and
@@ -25,6 +36,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .bk_core import BKCoreFunction, FusedBKLayerFunction, FusedSpectralOutputFunction
+from .scan import fused_associative_scan
 
 
 class BKCoreLayer(nn.Module):
@@ -111,6 +123,67 @@ class BKCoreLayer(nn.Module):
             features = torch.clamp(features, -self.feature_clamp, self.feature_clamp)
         out = self.bk_scale * self.output_proj(features)
         return out if residual is None else residual + out
+
+
+class HybridGatedMixing(nn.Module):
+    def __init__(self, d_model: int, soft_cap: float = 30.0):
+        super().__init__()
+        self.gate_sensitivity = nn.Parameter(torch.tensor(1.0))            # hybrid_attention.py:52
+        self.layer_norm = nn.LayerNorm(d_model, eps=1e-5)                  # :55
+        self.soft_cap = soft_cap                                           # :58
+
+    def _cap(self, t: torch.Tensor) -> torch.Tensor:                       # :84-86, :110-112
+        t = torch.tanh(t / self.soft_cap) * self.soft_cap
+        return torch.nan_to_num(t, nan=0.0, posinf=self.soft_cap, neginf=-self.soft_cap)
+
+    def forward(self, local_out: torch.Tensor, global_out: torch.Tensor, g_ii: torch.Tensor) -> torch.Tensor:
+        """local_out, global_out (B, N, D): the two mixing paths before their soft caps, capped in the dtype they
+        arrive in (bfloat16 under the reference's autocast); g_ii (B, N, 1) complex."""
+        local_out, global_out = self._cap(local_out), self._cap(global_out)
+        energy = torch.clamp(g_ii.imag.abs(), max=100.0)                   # :117-121
+        g = torch.sigmoid(energy * self.gate_sensitivity)                  # :122
+        self.last_gate_mean = g.detach().mean()
+        out = g * local_out + (1 - g) * global_out                         # :141
+        out = torch.nan_to_num(out, nan=0.0, posinf=self.soft_cap, neginf=-self.soft_cap)
+        return self.layer_norm(out)                                        # :143
+
+
+class BKHybridLayer(BKCoreLayer):
+    """x -> v_proj -> operator -> G_ii -> gate between a local and a global mixing path of x.  ``output_proj`` and
+    ``bk_scale`` exist (as in the reference layer, whose state_dict has them) and are unused on this path."""
+
+    def __init__(self, d_model: int, n_seq: int, num_heads: int = 8, window: int = 32, rank: int = 16,
+                 v_max: float = 5.0, fused: bool = False):
+        super().__init__(d_model, n_seq, v_max=v_max, feature_clamp=5.0, fused=fused)
+        if d_model % num_heads:
+            raise ValueError("d_model must be a multiple of num_heads")
+        self.num_heads, self.window = num_heads, window
+        self.hybrid_attn = HybridGatedMixing(d_model)
+        # stand-ins for HyperbolicMultiHeadAttention (windowed, causal) and AdaptiveRankSemiseparableLayer
+        self.local_qkv = nn.Linear(d_model, 3 * d_model, bias=False)
+        self.local_out = nn.Linear(d_model, d_model, bias=False)
+        self.global_in = nn.Linear(d_model, rank, bias=False)
+        self.global_out = nn.Linear(rank, d_model)
+
+    def local_path(self, x: torch.Tensor) -> torch.Tensor:
+        B, N, D = x.shape
+        W = self.window
+        pad = (W - N % W) % W                                              # hybrid_attention.py:93-100
+        xp = F.pad(x, (0, 0, 0, pad)) if pad else x
+        nw = xp.shape[1] // W
+        q, k, v = self.local_qkv(xp).reshape(B * nw, W, 3, self.num_heads, D // self.num_heads).permute(2, 0, 3, 1, 4)
+        o = F.scaled_dot_product_attention(q, k, v, is_causal=True)        # causal inside each window (:103)
+        return self.local_out(o.transpose(1, 2).reshape(B, nw * W, D))[:, :N]
+
+    def global_path(self, x: torch.Tensor) -> torch.Tensor:
+        u = self.global_in(x)                                              # (B, N, rank)
+        csum = fused_associative_scan(u, dim=1) if u.is_cuda else torch.cumsum(u, dim=1)   # ar_ssm_layer.py:517-525
+        pos = torch.arange(1, x.shape[1] + 1, device=x.device, dtype=u.dtype)
+        return self.global_out(csum / pos[None, :, None])
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _, G_ii = self.spectral_features(x)                                # the features are not used on this path
+        return self.hybrid_attn(self.local_path(x), self.global_path(x), G_ii)
 
 
 class CUDAOptimizedBKCore(nn.Module):

@@ -1414,6 +1414,11 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
   if (state && !SAVE)
     split_plan(B, N, (flags & BKCORE_FLAG_SCAN_PATH) ? CHUNK : bkcore_internal_ratio_chunk(), S, seg_ch);
   static const int legacy_split = [] { const char *e = getenv("BKCORE_SPLIT_LEGACY"); return e ? atoi(e) : 0; }();
+  // development: BKCORE_FORCE_CHUNKS=1 takes the one-workgroup-per-chunk form whatever the row count
+  static const int force_chunks = [] { const char *e = getenv("BKCORE_FORCE_CHUNKS"); return e ? atoi(e) : 0; }();
+  if (force_chunks && state && !SAVE && !(flags & (BKCORE_FLAG_SCAN_PATH | BKCORE_FLAG_ADAPTIVE)) &&
+      N >= 2 * bkcore_internal_ratio_chunk() && B * ((N + 4095) / 4096) < 2000000000LL)
+    S = 2;
   if (S > 1 && !(flags & BKCORE_FLAG_SCAN_PATH) && !legacy_split) {
     // few long rows, ratio form: one workgroup per chunk, the running product handed from chunk to chunk inside the
     // launch; then the (normally empty) launch of the scan kernel for rows whose checks failed

@@ -95,3 +95,35 @@ def test_training_steps_on_gpu_reduce_the_loss():
     assert losses[-1] < losses[0]
     gv = model.blocks[0].bk_layer.v_proj.weight.grad
     assert gv is not None and torch.isfinite(gv).all() and gv.abs().max() > 0
+
+
+def _tool_worker(rank, world, port, hybrid, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    import train_step_c5
+    argv = ["--device", "cpu", "--steps", "3", "--warmup", "1", "--batch", "2", "--vocab", "101", "--d-model", "16",
+            "--layers", "2", "--n-seq", "24"] + (["--hybrid"] if hybrid else [])
+    line = train_step_c5.main(argv, operator=_OracleOp.apply)
+    if rank == 0:
+        out["line"] = line
+    else:
+        assert line is None
+
+
+@pytest.mark.parametrize("hybrid", [False, True])
+def test_training_step_tool_control_flow_on_two_cpu_ranks(hybrid):
+    """tools/train_step_c5.py (BASELINE configs[4]'s driver: one process per GPU, DistributedDataParallel, barrier-
+    bracketed timing, MAX over ranks, one JSON line from rank 0) on two gloo ranks with the oracle as the operator.
+    hybrid: the layer of configs/phase7_small.yaml, whose unused parameters DDP must be told about."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_tool_worker, args=(2, port, hybrid, out), nprocs=2, join=True)
+        line = out["line"]
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["hybrid"] == hybrid and line["device"] == "cpu"
+    assert line["config"]["parallelism"] == "dp2"
+    assert np.isfinite(line["final_loss"]) and abs(line["final_loss"] - np.log(101)) < 1.0
+    assert line["value"] > 0 and line["ms_per_step"] > 0
