@@ -30,6 +30,9 @@ _DEBUG = {"keep_ws": False, "last_ws": None, "last_B": 0, "scan_path": False, "r
 _state = {}  # (device index, stream handle) -> persistent int32 state block for the NaN-sanitiser corner
 _ws = {}     # (device index, stream handle) -> workspace tensor, grown on demand and reused by every call on the stream
 _ws_bytes = {}  # (B, N) -> bkcore_workspace_bytes(B, N)
+_ws_ana = {}    # the same two for the analytic backward
+_ws_ana_bytes = {}
+_ws_retired = []  # workspaces that a larger one superseded: kept, because a captured graph may still point at them
 
 
 def _state_block(device: torch.device, stream: int) -> torch.Tensor:
@@ -41,19 +44,31 @@ def _state_block(device: torch.device, stream: int) -> torch.Tensor:
     return blk
 
 
+def _cached_workspace(cache: dict, device: torch.device, stream: int, need: int) -> torch.Tensor:
+    """One buffer per (device, stream): calls on one stream execute in order, so it serves them all (every call on the
+    stream shares it; it is written before it is read by each).  It only ever grows, and a buffer that a larger one
+    supersedes is kept rather than freed: a HIP graph captured on this stream earlier holds its address.  While the
+    stream is being captured the call gets a buffer of its own from the graph's memory pool instead -- the cached one
+    belongs to eager calls, which may run concurrently with replays."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(need, 256), dtype=torch.uint8, device=device)
+    key = (device.index, stream)
+    ws = cache.get(key)
+    if ws is None or ws.numel() < need:
+        if ws is not None:
+            _ws_retired.append(ws)
+        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=device)
+        cache[key] = ws
+    return ws
+
+
 def _workspace(L, device: torch.device, stream: int, B: int, N: int):
-    """(tensor, bytes needed).  Calls on one stream execute in order, so one buffer per (device, stream) serves them
-    all; it only ever grows.  The size query is cached per shape."""
+    """(tensor, bytes needed) for the forward.  The size query is cached per shape."""
     need = _ws_bytes.get((B, N))
     if need is None:
         need = int(L.bkcore_workspace_bytes(B, N))
         _ws_bytes[(B, N)] = need
-    key = (device.index, stream)
-    ws = _ws.get(key)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=device)
-        _ws[key] = ws
-    return ws, need
+    return _cached_workspace(_ws, device, stream, need), need
 
 
 class _on_device:
@@ -125,6 +140,9 @@ def _prep_z(z, device):
         raise ValueError("bkcore: z must hold exactly one value")
     if z.is_cuda:
         # a complex64 element is the (re, im) float pair the kernels read: no view, no copy, no host sync
+        # (a lazily conjugated or negated tensor keeps its bits un-conjugated in storage: materialise it first)
+        if z.is_conj() or z.is_neg():
+            z = z.resolve_conj().resolve_neg()
         if z.dtype == torch.complex64 and z.device == device:
             return z, z.data_ptr(), 0.0, 0.0
         zz = z.detach().reshape(()).to(device=device, dtype=torch.complex64)
@@ -384,8 +402,14 @@ def bk_backward_analytic(a, b, c, z, grad_features, grad_G, phi_exact: bool = Fa
         stream = torch.cuda.current_stream().cuda_stream
         zkeep, pz, zre, zim = _prep_z(z, a.device)
         state = _state_block(a.device, stream)
-        ws_bytes = int(L.bkcore_backward_analytic_workspace_bytes(B, N))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
+        ws_bytes = _ws_ana_bytes.get((B, N))
+        if ws_bytes is None:
+            ws_bytes = int(L.bkcore_backward_analytic_workspace_bytes(B, N))
+            _ws_ana_bytes[(B, N)] = ws_bytes
+        if _DEBUG["keep_ws"]:       # diagnostics read the workspace after the call: give this call its own
+            ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=a.device)
+        else:
+            ws = _cached_workspace(_ws_ana, a.device, stream, ws_bytes)
         rc = L.bkcore_backward_analytic(pa, lda, pb if nb else None, ldb, pc if nb else None, ldc, pz, zre, zim, B, N,
                                         gsaved.data_ptr() if gsaved is not None else None,
                                         gf.data_ptr() if gf is not None else None,

@@ -5,9 +5,12 @@
   :91,188); backward = ``compute_single_gradient`` (:12-54) for he_diag, ``None`` for the rest.  The reference's two
   classes differ only in how the batch is cut up on the host (vmap over rows / chunks of 32 rows); one launch here.
 * ``BKScanStableFunction`` (src/kernels/bk_scan_stable.py:556-611): ``apply(a, b, c, z_real, z_imag) -> G`` complex64;
-  backward ``grad_a = -Re(g) |G|^2`` (:597), zeros for b and c (:605-609).  The reference evaluates the forward in
-  log-polar arithmetic (:39-314), an overflow-proof evaluation of the same recurrence; here it is the operator's own
-  forward in get-diag mode, whose scaled arithmetic does not overflow either.
+  backward ``grad_a = -Re(g) |G|^2`` (:597), zeros for b and c (:605-609): that backward is what is reproduced.
+  The reference's forward there (log-polar arithmetic, :39-314) is NOT the operator's recurrence: it keeps
+  ``phi_raw[:, 1:].flip(1)`` (:284), i.e. the trailing minor of size N - i where the resolvent diagonal needs size
+  N - 1 - i (its G_00 comes out as 1), and it has no diagonal regularisation.  Its numbers are neither the oracle's nor
+  the resolvent's and are not matched; the forward here is the operator's own in get-diag mode
+  (src/models/bk_core.py:27-210 semantics), whose scaled arithmetic is overflow-proof as well.
 """
 from __future__ import annotations
 

@@ -65,3 +65,18 @@ def test_noalloc_rejects_sizes_beyond_its_scratch():
                                   B, N, x.data_ptr(), None, 0.0, 0, torch.cuda.current_stream().cuda_stream)
     assert rc == _lib.ETOOBIG
     assert b"BKCORE_NOALLOC_MAX_WORKSPACE" in L.bkcore_error_string(rc)
+
+
+def test_noalloc_first_call_inside_graph_capture():
+    """The callers this entry point is for include code under HIP graph capture.  In a fresh process (so that the
+    call inside the capture is the first on the device and looks the scratch array's address up there): capture,
+    replay on clean and NaN-poisoned inputs, compare bit for bit with bkcore_forward_clamped."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import os
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "noalloc_graph_child.py")
+    r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "bitwise equal on 3 replays" in r.stdout
