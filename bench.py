@@ -266,8 +266,14 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    rank_ms = [dt / args.steps * 1e3]
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        # every rank's own time (a later scaling run shows skew between ranks), then the MAX that is reported
+        mine = torch.tensor([dt], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        tt = mine.clone()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -283,6 +289,10 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms,
+            "ms_per_step_ranks": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
+            "world": {"env_world_size": world,
+                      "torch_distributed_world_size": dist.get_world_size() if world > 1 else 1,
+                      "backend": (dist.get_backend() if world > 1 else None)},
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
@@ -446,7 +456,10 @@ def secondary_measurements(torch, bkcore, device, B, N, ad, b, c, z, gfeat, time
         "analytic_backward_ms": t_ana * 1e3,
         "analytic_backward_note": "grad for he_diag, h0_super, h0_sub",
         "long_context_B16_N1048576": {"fwd_ms": t3f * 1e3, "bwd_ms": t3b * 1e3,
-                                      "diag_elems_per_sec": 16 * (1 << 20) / (t3f + t3b)},
+                                      "diag_elems_per_sec": 16 * (1 << 20) / (t3f + t3b),
+                                      "fwd_frac": FWD_BYTES * 16 * (1 << 20) / t3f / HBM_PEAK,
+                                      "fwd_bwd_frac": (FWD_BYTES + BWD_BYTES) * 16 * (1 << 20) / (t3f + t3b) / HBM_PEAK,
+                                      "launches_per_forward": 2},
     }
     return out
 

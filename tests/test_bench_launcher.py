@@ -24,6 +24,10 @@ def test_two_ranks_spawned_weak_scaling():
     assert out["config"]["rows_per_gpu"] == 8
     # whole-job rate: both ranks' rows over the slowest rank's time
     assert abs(out["value"] - 2 * 8 * 512 / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
+    # every rank's own time beside the reported maximum, and the world torch.distributed itself reports
+    r = out["ms_per_step_ranks"]
+    assert len(r["per_rank"]) == 2 and r["max"] == max(r["per_rank"]) and abs(r["max"] - out["ms_per_step"]) < 1e-9
+    assert out["world"] == {"env_world_size": 2, "torch_distributed_world_size": 2, "backend": "gloo"}
 
 
 def test_two_ranks_rows_sharded():
