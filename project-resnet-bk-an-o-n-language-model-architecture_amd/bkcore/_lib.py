@@ -18,12 +18,13 @@ FLAG_ROW_UNITS = 16
 FLAG_ROW_UNITS_MANY = 32
 FLAG_ROW_UNITS_MUTE = 64
 STATE_BYTES = 64
-ABI_VERSION = 15
+ABI_VERSION = 16
 EINVAL, ETOOLONG, ELAUNCH, EWORKSPACE, ETOOBIG = -1, -2, -3, -4, -5
 BWD_REFERENCE, BWD_BATCHED, BWD_SCAN_STABLE = 0, 1, 2
 NOALLOC_MAX_WORKSPACE = 8 << 20
 
-EXPORTS = ("bkcore_forward", "bkcore_forward_clamped", "bkcore_forward_noalloc", "bkcore_workspace_bytes", "bkcore_backward_ref", "bkcore_backward_ref_flagged", "bkcore_backward_variant", "bkcore_backward_analytic",
+EXPORTS = ("bkcore_forward", "bkcore_forward_clamped", "bkcore_forward_noalloc", "bkcore_forward_states",
+           "bkcore_boundary_state_bytes", "bkcore_backward_analytic_states", "bkcore_workspace_bytes", "bkcore_backward_ref", "bkcore_backward_ref_flagged", "bkcore_backward_variant", "bkcore_backward_analytic",
            "bkcore_backward_analytic_workspace_bytes", "bkcore_backward_analytic_rowflag_offset", "bkcore_layer_prologue", "bkcore_layer_backward_ref",
            "bkcore_layer_epilogue", "bkcore_layer_epilogue_backward", "bkcore_layer_epilogue_backward_workspace_bytes",
            "bkcore_layer_epilogue_clamped", "bkcore_layer_epilogue_backward_clamped", "bkcore_cumsum", "bkcore_woodbury_correct", "bkcore_woodbury_workspace_bytes",
@@ -63,6 +64,14 @@ def load():
     L.bkcore_backward_analytic.argtypes = [vp, i64, vp, i64, vp, i64, vp, f32, f32, i64, i64, vp, vp, vp, vp, vp, vp,
                                            vp, ctypes.c_size_t, vp, ctypes.c_uint, vp]
     L.bkcore_backward_analytic.restype = i32
+    L.bkcore_backward_analytic_states.argtypes = [vp, i64, vp, i64, vp, i64, vp, f32, f32, i64, i64, vp, vp, vp, vp, vp,
+                                                  vp, vp, vp, ctypes.c_size_t, vp, ctypes.c_uint, vp]
+    L.bkcore_backward_analytic_states.restype = i32
+    L.bkcore_forward_states.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp, f32, f32, i64, i64, vp, vp, f32, vp,
+                                        ctypes.POINTER(ctypes.c_int), vp, ctypes.c_size_t, vp, ctypes.c_uint, vp]
+    L.bkcore_forward_states.restype = i32
+    L.bkcore_boundary_state_bytes.argtypes = [i64, i64]
+    L.bkcore_boundary_state_bytes.restype = ctypes.c_size_t
     L.bkcore_backward_analytic_workspace_bytes.argtypes = [i64, i64]
     L.bkcore_backward_analytic_workspace_bytes.restype = ctypes.c_size_t
     L.bkcore_backward_analytic_rowflag_offset.argtypes = [i64, i64]

@@ -584,6 +584,7 @@ constexpr int ROUNDS = (SN + T - 1) / T;
 struct Raw {
   float av[ROUNDS], bv[ROUNDS], cv[ROUNDS];
   float2 Gv[EB], gv[EB];
+  float4 st;  // the lane's boundary states kept by the forward: om(r) entering its block, om(s) two elements past it
 };
 
 // CHECK = false when every staged element and its off-diagonal entries lie inside the row.  Addresses are a uniform
@@ -591,7 +592,10 @@ struct Raw {
 template <bool CHECK>
 __device__ __forceinline__ void issue_loads(const float *__restrict__ a, const float *__restrict__ b,
                                             const float *__restrict__ c, const float *__restrict__ G,
-                                            const float *__restrict__ gf, long base, long N, Raw &R, int t) {
+                                            const float *__restrict__ gf, const float4 *__restrict__ bst, long base,
+                                            long N, Raw &R, int t) {
+  R.st = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bst && base + (long)t * EB < N) R.st = bst[base / EB + t];
   const float *__restrict__ pa = a + (base - WH);       // slot q: a[base - WH + q]
   const float *__restrict__ pb = b + (base - WH - 1);   // slot q holds k_{i-1}, i = base - WH + q
   const float *__restrict__ pc = c + (base - WH - 1);
@@ -634,9 +638,10 @@ __device__ __forceinline__ void issue_loads(const float *__restrict__ a, const f
 }
 __device__ __forceinline__ void issue_chunk(const float *__restrict__ a, const float *__restrict__ b,
                                             const float *__restrict__ c, const float *__restrict__ G,
-                                            const float *__restrict__ gf, long base, long N, Raw &R, int t) {
-  if (base - WH - 1 >= 0 && base + CHUNK + WH - 1 <= N - 1) issue_loads<false>(a, b, c, G, gf, base, N, R, t);
-  else issue_loads<true>(a, b, c, G, gf, base, N, R, t);
+                                            const float *__restrict__ gf, const float4 *__restrict__ bst, long base,
+                                            long N, Raw &R, int t) {
+  if (base - WH - 1 >= 0 && base + CHUNK + WH - 1 <= N - 1) issue_loads<false>(a, b, c, G, gf, bst, base, N, R, t);
+  else issue_loads<true>(a, b, c, G, gf, bst, base, N, R, t);
 }
 
 // Writes a chunk's staged form: regularised diagonal and off-diagonal products with their halo, q, and for the
@@ -689,14 +694,18 @@ __device__ __forceinline__ float2 shift2(float2 v) {  // lane shift by DPP, 0 wh
   return make_float2(dpp_f<CTRL, 0xF>(0.0f, v.x), dpp_f<CTRL, 0xF>(0.0f, v.y));
 }
 
-template <int OFF>  // kphi_m = k_{m-OFF}
+// SAVED: the ratio chains start from the boundary states the forward kept (bst_: per block of EB elements the om(r)
+// entering it and the om(s) two elements past it) instead of running a 16-step warm-up on either side; the checks
+// between neighbouring lanes stay, now comparing the forward's value with the one recomputed from the block before.
+template <int OFF, bool SAVED>  // kphi_m = k_{m-OFF}
 __global__ __launch_bounds__(T, BK_SWEEP_WG) void bk_adjoint_sweeps(
     const float *__restrict__ a_, long lda, const float *__restrict__ b_, long ldb, const float *__restrict__ c_,
     long ldc, const float *__restrict__ z_dev, float z_re, float z_im, long N, const float *__restrict__ G_,
     const float *__restrict__ gf_, const float *__restrict__ gG_, float *__restrict__ ga_, float *__restrict__ gb_,
     float *__restrict__ gc_, int *__restrict__ rowbad, int *state, unsigned long long *dbg, int S, long seg_len,
-    const double2 *__restrict__ segsum) {
+    const double2 *__restrict__ segsum, const float4 *__restrict__ bst_) {
   __shared__ SharedSweep sh;
+  static_assert(EB == 8, "the forward keeps its boundary states per block of 8 elements");
   // Few long rows: a row is cut into S segments of seg_len elements, one workgroup each.  A
   // segment after the first starts two lanes early: mu enters those lanes as 0, which reaches only them (their results
   // belong to the segment before), exactly as lam does at the end of every chunk; the sum of q over everything before
@@ -713,6 +722,7 @@ __global__ __launch_bounds__(T, BK_SWEEP_WG) void bk_adjoint_sweeps(
   float *gb = gb_ ? gb_ + row * (N - 1) : nullptr;
   float *gc = gc_ ? gc_ + row * (N - 1) : nullptr;
   const float2 z = z_dev ? make_float2(z_dev[0], z_dev[1]) : make_float2(z_re, z_im);
+  const float4 *bst = SAVED ? bst_ + row * ((N + EB - 1) / EB) : nullptr;
   const int t = threadIdx.x;
   const int nch = N <= CHUNK ? 1 : 1 + (int)((N - CHUNK + STRIDE - 1) / STRIDE);  // (index of the debug stamps)
   (void)nch;
@@ -729,7 +739,7 @@ __global__ __launch_bounds__(T, BK_SWEEP_WG) void bk_adjoint_sweeps(
     sh.xc_p[1][1] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   Raw R;
-  if (BK_SWEEP_PREFETCH) issue_chunk(a, b, c, G, gf, start, N, R, t);
+  if (BK_SWEEP_PREFETCH) issue_chunk(a, b, c, G, gf, bst, start, N, R, t);
   bool more = true;
   for (int cc = 0; more; ++cc) {
     const int buf = cc & 1;
@@ -742,7 +752,7 @@ __global__ __launch_bounds__(T, BK_SWEEP_WG) void bk_adjoint_sweeps(
     // they are used instead of being kept in registers across the whole loop)
     int ts = t;
     asm volatile("" : "+v"(ts));
-    if (!BK_SWEEP_PREFETCH) issue_chunk(a, b, c, G, gf, base, N, R, ts);
+    if (!BK_SWEEP_PREFETCH) issue_chunk(a, b, c, G, gf, bst, base, N, R, ts);
     __syncthreads();  // every lane finished reading the staging area
     commit_chunk(R, gG, base, N, z, sh, ts);
     __syncthreads();
@@ -758,9 +768,27 @@ __global__ __launch_bounds__(T, BK_SWEEP_WG) void bk_adjoint_sweeps(
     // the batch before it.  Ratio chains: warm-up over the WH elements before the lane's own in the direction of the
     // recurrence (theta: to the left; phi: to the right, where past the end of the row the staged values give om * 0),
     // then the lane's own.  kphi_d = k_{d-OFF} sits in slot d + 1 - OFF and is 0 from the last element on.
-    float2 alt[WH], alp[WH], alo[EB];
-    float kt[WH], kp[WH], kx[EB + 2];  // kx[x] = slot x - 1
+    float2 alo[EB];
+    float kx[EB + 2];  // kx[x] = slot x - 1
     float2 omt = make_float2(0.f, 0.f), omp = make_float2(0.f, 0.f);
+    float2 inv8 = make_float2(0.f, 0.f), om9 = make_float2(0.f, 0.f);  // phi at elements 8 and 9 of the lane
+    float wc8 = 0.0f, tau8 = 0.0f;
+    if constexpr (SAVED) {
+      const float4 sv = R.st;
+#pragma unroll
+      for (int e = 0; e < EB; ++e) alo[e] = al_l[soff(e)];
+#pragma unroll
+      for (int x = 0; x < EB + 2; ++x) kx[x] = k_l[soff(x - 1)];
+      const float2 al8 = al_l[soff(EB)];
+      float k8 = k_l[soff(EB + 1 - OFF)];
+      if (tail && first + EB >= N - 1) k8 = 0.0f;
+      if (first > 0) omt = make_float2(sv.x, sv.y);                    // theta enters a row with om = 0
+      if (first + EB + 1 <= N - 1) om9 = make_float2(sv.z, sv.w);      // phi likewise, from the other end
+      float lv = 0.0f;
+      omp = om_full(al8, k8, om9, inv8, wc8, tau8, lv);
+    } else {
+    float2 alt[WH], alp[WH];
+    float kt[WH], kp[WH];
 #pragma unroll
     for (int j = 0; j < WH / 2; ++j) {
       alt[j] = al_l[soff(j - WH)];
@@ -796,8 +824,6 @@ __global__ __launch_bounds__(T, BK_SWEEP_WG) void bk_adjoint_sweeps(
       for (int j = WH / 2; j < WH; ++j)
         if (first + (EB + WH - 1 - j) >= N - 1) kp[j] = 0.0f;
     }
-    float2 inv8 = make_float2(0.f, 0.f), om9 = make_float2(0.f, 0.f);  // phi at elements 8 and 9 of the lane
-    float wc8 = 0.0f, tau8 = 0.0f;
 #pragma unroll
     for (int j = WH / 2; j < WH; ++j) {
       if (j < 3 * WH / 4) {
@@ -810,6 +836,7 @@ __global__ __launch_bounds__(T, BK_SWEEP_WG) void bk_adjoint_sweeps(
         if (j == WH - 1) om9 = omp;
         omp = om_full(alp[j], kp[j], omp, inv8, wc8, tau8, lv);
       }
+    }
     }
     __builtin_amdgcn_sched_barrier(0);
     float2 q[EB];
@@ -890,7 +917,7 @@ __global__ __launch_bounds__(T, BK_SWEEP_WG) void bk_adjoint_sweeps(
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e <= EB; ++e) pre[e] = cadd(pre[e], run);  // pre[e] = P_{first + e - 1}
-    if (BK_SWEEP_PREFETCH && more) issue_chunk(a, b, c, G, gf, base + STRIDE, N, R, tl);
+    if (BK_SWEEP_PREFETCH && more) issue_chunk(a, b, c, G, gf, bst, base + STRIDE, N, R, tl);
     __builtin_amdgcn_sched_barrier(0);
     // the lane's maps applied to 0 and the product of their linear parts, for both adjoints:
     //   mu  (left -> right): c0 = P_{j-1},  off-diagonal product kphi_{j-1} = slot e - OFF
@@ -1133,6 +1160,17 @@ int bkcore_backward_analytic(const float *a, int64_t lda, const float *b, int64_
                              const float *grad_features, const float *grad_G, float *grad_a, float *grad_b,
                              float *grad_c, void *workspace, size_t workspace_bytes, void *state, unsigned flags,
                              void *stream) {
+  return bkcore_backward_analytic_states(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G_saved, nullptr,
+                                         grad_features, grad_G, grad_a, grad_b, grad_c, workspace, workspace_bytes,
+                                         state, flags, stream);
+}
+
+int bkcore_backward_analytic_states(const float *a, int64_t lda, const float *b, int64_t ldb, const float *c,
+                                    int64_t ldc, const float *z_dev, float z_re, float z_im, int64_t B, int64_t N,
+                                    const float *G_saved, const float *boundary_states, const float *grad_features,
+                                    const float *grad_G, float *grad_a, float *grad_b, float *grad_c, void *workspace,
+                                    size_t workspace_bytes, void *state, unsigned flags, void *stream) {
+  if (boundary_states && !G_saved) return BKCORE_EINVAL;  // the states belong to the forward call that produced G
   if (B < 0 || N < 0 || lda < 0 || ldb < 0 || ldc < 0) return BKCORE_EINVAL;
   if (B == 0 || N == 0) return BKCORE_OK;
   if (!a || !grad_a || (N > 1 && (!b || !c))) return BKCORE_EINVAL;
@@ -1172,14 +1210,17 @@ int bkcore_backward_analytic(const float *a, int64_t lda, const float *b, int64_
     if (S > 1)
       hipLaunchKernelGGL(bk_adjoint_segsum, dim3((unsigned)(B * S)), dim3(T), 0, s, G, grad_features, grad_G, (long)N,
                          S, seg_len, segsum, rowbad);
-#define BK_LAUNCH_SWEEPS(OFF)                                                                                         \
-  hipLaunchKernelGGL((bk_adjoint_sweeps<OFF>), dim3((unsigned)(B * S)), dim3(T), 0, s, a, (long)lda, b, (long)ldb,   \
-                     c, (long)ldc, z_dev, z_re, z_im, (long)N, G, grad_features, grad_G, grad_a, gk, gc, rowbad, st,  \
-                     (unsigned long long *)sr, S, seg_len, (const double2 *)segsum)
+#define BK_LAUNCH_SWEEPS(OFF, SAVEDV)                                                                                 \
+  hipLaunchKernelGGL((bk_adjoint_sweeps<OFF, SAVEDV>), dim3((unsigned)(B * S)), dim3(T), 0, s, a, (long)lda, b,      \
+                     (long)ldb, c, (long)ldc, z_dev, z_re, z_im, (long)N, G, grad_features, grad_G, grad_a, gk, gc,   \
+                     rowbad, st, (unsigned long long *)sr, S, seg_len, (const double2 *)segsum,                       \
+                     (const float4 *)boundary_states)
     if (flags & BKCORE_FLAG_PHI_EXACT) {
-      BK_LAUNCH_SWEEPS(0);
+      if (boundary_states) BK_LAUNCH_SWEEPS(0, true);
+      else BK_LAUNCH_SWEEPS(0, false);
     } else {
-      BK_LAUNCH_SWEEPS(1);
+      if (boundary_states) BK_LAUNCH_SWEEPS(1, true);
+      else BK_LAUNCH_SWEEPS(1, false);
     }
 #undef BK_LAUNCH_SWEEPS
     filter = rowbad;

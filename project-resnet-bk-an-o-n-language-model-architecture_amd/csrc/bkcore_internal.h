@@ -22,17 +22,16 @@ extern "C" __attribute__((visibility("hidden"))) int bkcore_internal_forward_sav
 // Launches of the ratio-form forward (bkcore_ratio.hip); errors are left for the caller's hipGetLastError().
 // mode 3: rows cut into S units of seg_ch chunks that hand over inside ONE launch; `save` then carries the number of
 // workgroups the GPU holds at once (the grid is at most that).
-// mode 0: one workgroup per row (save != 0: the variant that also stores r, s and writes G_raw); mode 1 / 2: per-segment
-// products / per-segment outputs of rows cut into S segments of seg_ch chunks, around bkcore_internal_ratio_combine.
+// mode 0: one workgroup per row (save == 1: the variant that also stores r, s and writes G_raw; save == 2: the variant
+// that stores the boundary states of the analytic backward into save_r).  mode 4: one workgroup per chunk, S = chunks per
+// row, handing the running product over inside the launch.  With mode 4 a non-null save_r selects the variant that
+// stores the boundary states there (float32 operands, float32 chains only; not available with mode 3).
 extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_ratio_forward(
     int in_dtype, int phi_exact, int mode, int save, const void *a, int64_t lda, const void *b, int64_t ldb,
     const void *c, int64_t ldc, const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G,
     float *features, void *ws, void *state, unsigned flags, float fclamp, int S, int seg_ch, float *save_r,
     float *save_s, void *stream);
-extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_ratio_combine(int64_t B, int64_t N, void *ws,
-                                                                                   void *state, int S,
-                                                                                   void *stream);
-// The same two launches with double-precision chains and product (bkcore_ratio_long.hip; no saving variant), taken for
+// The same launch with double-precision chains and product (bkcore_ratio_long.hip; no saving variant), taken for
 // rows longer than BKCORE_INTERNAL_LONG_ROW elements.
 #define BKCORE_INTERNAL_LONG_ROW 131072
 extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_ratio_forward_long(
@@ -40,9 +39,6 @@ extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_ratio_forw
     const void *c, int64_t ldc, const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G,
     float *features, void *ws, void *state, unsigned flags, float fclamp, int S, int seg_ch, float *save_r,
     float *save_s, void *stream);
-extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_ratio_combine_long(int64_t B, int64_t N, void *ws,
-                                                                                        void *state, int S,
-                                                                                        void *stream);
 // Workgroups of the mode 3 kernel one CU holds at once on the current device (0: unknown).
 extern "C" __attribute__((visibility("hidden"))) int bkcore_internal_ratio_unit_occupancy(int in_dtype, int phi_exact);
 // Elements per chunk of the ratio-form kernel (its workgroup size x 16).

@@ -1404,7 +1404,7 @@ template <typename TIn, bool PHI_EXACT, bool SAVE>
 int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
                     const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
                     void *ws, void *state, unsigned flags, hipStream_t stream, float *save_r, float *save_s,
-                    float fclamp = __builtin_huge_valf()) {
+                    float fclamp = __builtin_huge_valf(), float *bstates = nullptr) {
 #define BK_LAUNCH(FASTV, SECOND)                                                                                     \
   hipLaunchKernelGGL((bk_forward_kernel<TIn, PHI_EXACT, FASTV, SAVE>), dim3((unsigned)B), dim3(T), 0, stream,        \
                      (const TIn *)a, (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re,   \
@@ -1413,42 +1413,21 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
   int S = 1, seg_ch = 0;
   if (state && !SAVE)
     split_plan(B, N, (flags & BKCORE_FLAG_SCAN_PATH) ? CHUNK : bkcore_internal_ratio_chunk(), S, seg_ch);
-  static const int legacy_split = [] { const char *e = getenv("BKCORE_SPLIT_LEGACY"); return e ? atoi(e) : 0; }();
   // development: BKCORE_FORCE_CHUNKS=1 takes the one-workgroup-per-chunk form whatever the row count
   static const int force_chunks = [] { const char *e = getenv("BKCORE_FORCE_CHUNKS"); return e ? atoi(e) : 0; }();
   if (force_chunks && state && !SAVE && !(flags & (BKCORE_FLAG_SCAN_PATH | BKCORE_FLAG_ADAPTIVE)) &&
       N >= 2 * bkcore_internal_ratio_chunk() && B * ((N + 4095) / 4096) < 2000000000LL)
     S = 2;
-  if (S > 1 && !(flags & BKCORE_FLAG_SCAN_PATH) && !legacy_split) {
+  if (S > 1 && !(flags & BKCORE_FLAG_SCAN_PATH)) {
     // few long rows, ratio form: one workgroup per chunk, the running product handed from chunk to chunk inside the
     // launch; then the (normally empty) launch of the scan kernel for rows whose checks failed
     const auto fwd = N > BKCORE_INTERNAL_LONG_ROW ? bkcore_internal_ratio_forward_long : bkcore_internal_ratio_forward;
     const int nch = (int)((N + bkcore_internal_ratio_chunk() - 1) / bkcore_internal_ratio_chunk());
     fwd(dtype_tag<TIn>(), PHI_EXACT, 4, 0, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
-        flags, fclamp, nch, 1, nullptr, nullptr, stream);
+        flags, fclamp, nch, 1, bstates, nullptr, stream);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) {
       BK_LAUNCH(false, 3 | (nch << 2));
-      err = hipGetLastError();
-    }
-    if (err != hipSuccess) {
-      g_last_hip_error = (int)err;
-      return BKCORE_ELAUNCH;
-    }
-  } else if (S > 1 && !(flags & BKCORE_FLAG_SCAN_PATH)) {
-    // (development: BKCORE_SPLIT_LEGACY=1) segment products, combine, segment outputs, then the (normally empty)
-    // launch of the scan kernel for rows whose checks failed
-    // rows beyond BKCORE_INTERNAL_LONG_ROW elements: chains and product in double
-    const auto fwd = N > BKCORE_INTERNAL_LONG_ROW ? bkcore_internal_ratio_forward_long : bkcore_internal_ratio_forward;
-    const auto comb = N > BKCORE_INTERNAL_LONG_ROW ? bkcore_internal_ratio_combine_long : bkcore_internal_ratio_combine;
-    fwd(dtype_tag<TIn>(), PHI_EXACT, 1, 0, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
-        flags, fclamp, S, seg_ch, nullptr, nullptr, stream);
-    comb(B, N, ws, state, S, stream);
-    fwd(dtype_tag<TIn>(), PHI_EXACT, 2, 0, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
-        flags, fclamp, S, seg_ch, nullptr, nullptr, stream);
-    hipError_t err = hipGetLastError();
-    if (err == hipSuccess) {
-      BK_LAUNCH(false, 1);
       err = hipGetLastError();
     }
     if (err != hipSuccess) {
@@ -1485,10 +1464,14 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
     // form must fit the GPU at once: its workgroups wait for each other); without an answer, whole rows
     const int per_cu = (!SAVE && N <= BKCORE_INTERNAL_LONG_ROW && !(flags & BKCORE_FLAG_ADAPTIVE))
                            ? bkcore_internal_ratio_unit_occupancy(dtype_tag<TIn>(), PHI_EXACT) : 0;
-    if (per_cu > 0) relay_plan(B, N, bkcore_internal_ratio_chunk(), per_cu, flags, RS, rseg);
+    // (the variant that keeps the boundary states holds fewer workgroups per CU and has no unit form: whole rows)
+    if (per_cu > 0 && !bstates) relay_plan(B, N, bkcore_internal_ratio_chunk(), per_cu, flags, RS, rseg);
     if (RS > 1)
       fwd(dtype_tag<TIn>(), PHI_EXACT, 3, per_cu * device_cu_count(), a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
           flags, fclamp, RS, rseg, nullptr, nullptr, stream);
+    else if (bstates && !SAVE)
+      fwd(dtype_tag<TIn>(), PHI_EXACT, 0, 2, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
+          flags, fclamp, 1, 0, bstates, nullptr, stream);
     else
       fwd(dtype_tag<TIn>(), PHI_EXACT, 0, SAVE, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
           flags, fclamp, 1, 0, save_r, save_s, stream);
@@ -1530,12 +1513,19 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
 template <typename TIn>
 int launch_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
                    const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
-                   void *ws, void *state, unsigned flags, hipStream_t s, float fclamp) {
+                   void *ws, void *state, unsigned flags, hipStream_t s, float fclamp, float *bstates = nullptr) {
   if (flags & BKCORE_FLAG_PHI_EXACT)
     return launch_forward2<TIn, true, false>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
-                                             flags, s, nullptr, nullptr, fclamp);
+                                             flags, s, nullptr, nullptr, fclamp, bstates);
   return launch_forward2<TIn, false, false>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
-                                            flags, s, nullptr, nullptr, fclamp);
+                                            flags, s, nullptr, nullptr, fclamp, bstates);
+}
+
+// Whether a forward call with these arguments takes a path that writes the boundary states: float32 operands, a state
+// block, the ratio form with float32 chains.
+bool forward_writes_states(int in_dtype, int64_t N, const void *state, unsigned flags) {
+  return in_dtype == BKCORE_F32 && state != nullptr && !(flags & (BKCORE_FLAG_SCAN_PATH | BKCORE_FLAG_ADAPTIVE)) &&
+         N <= BKCORE_INTERNAL_LONG_ROW;
 }
 
 }  // namespace
@@ -1591,6 +1581,36 @@ int bkcore_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const
                    void *workspace, size_t workspace_bytes, void *state, unsigned flags, void *stream) {
   return bkcore_forward_clamped(a, lda, b, ldb, c, ldc, in_dtype, z_dev, z_re, z_im, B, N, G, features, 0.0f, workspace,
                                 workspace_bytes, state, flags, stream);
+}
+
+size_t bkcore_boundary_state_bytes(int64_t B, int64_t N) {
+  if (B <= 0 || N <= 0) return 0;
+  return (size_t)B * (size_t)((N + 7) / 8) * 4 * sizeof(float);
+}
+
+int bkcore_forward_states(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc, int in_dtype,
+                          const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
+                          float feature_clamp, float *boundary_states, int *states_written, void *workspace,
+                          size_t workspace_bytes, void *state, unsigned flags, void *stream) {
+  if (states_written) *states_written = 0;
+  if (!boundary_states)
+    return bkcore_forward_clamped(a, lda, b, ldb, c, ldc, in_dtype, z_dev, z_re, z_im, B, N, G, features, feature_clamp,
+                                  workspace, workspace_bytes, state, flags, stream);
+  const float fclamp = feature_clamp > 0.0f ? feature_clamp : __builtin_huge_valf();
+  if (feature_clamp != feature_clamp) return BKCORE_EINVAL;
+  if (B < 0 || N < 0 || lda < 0 || ldb < 0 || ldc < 0) return BKCORE_EINVAL;
+  if (B == 0 || N == 0) return BKCORE_OK;
+  if (!a || !G || (N > 1 && (!b || !c))) return BKCORE_EINVAL;
+  if (N > bkcore_max_seq_len()) return BKCORE_ETOOLONG;
+  if (B > 2147483647LL) return BKCORE_EINVAL;
+  const size_t need = bkcore_workspace_bytes(B, N);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return BKCORE_EWORKSPACE;
+  if (!forward_writes_states(in_dtype, N, state, flags))
+    return bkcore_forward_clamped(a, lda, b, ldb, c, ldc, in_dtype, z_dev, z_re, z_im, B, N, G, features, feature_clamp,
+                                  workspace, workspace_bytes, state, flags, stream);
+  if (states_written) *states_written = 1;
+  return launch_forward<float>(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, workspace, state, flags,
+                               (hipStream_t)stream, fclamp, boundary_states);
 }
 
 int bkcore_forward_noalloc(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
@@ -1827,7 +1847,7 @@ int bkcore_forward_plan(int64_t B, int64_t N, int in_dtype, unsigned flags, int 
 }
 int bkcore_last_hip_error(void) { return g_last_hip_error; }
 void bkcore_internal_set_hip_error(int code) { g_last_hip_error = code; }
-int bkcore_abi_version(void) { return 15; }
+int bkcore_abi_version(void) { return 16; }
 
 const char *bkcore_error_string(int code) {
   switch (code) {

@@ -167,26 +167,6 @@ __device__ __forceinline__ Prod prod_dpp(const Prod &p) {  // identity where the
   r.e = dpp_i<CTRL, ROW_MASK>(0, p.e);
   return r;
 }
-// A product in a segment record: float32 mantissa in floats [at, at+1]; the double variant keeps its mantissa in the
-// 8-byte slots [at2, at2+3] of the record (records are 128-byte aligned).  Exponent as an int in float slot `ate`.
-__device__ __forceinline__ void put_prod(float *info, int at, int at2, int ate, const Prod &p) {
-  if (LONG) {
-    reinterpret_cast<double *>(info + at2)[0] = (double)p.m.x;
-    reinterpret_cast<double *>(info + at2)[1] = (double)p.m.y;
-  } else {
-    info[at] = (float)p.m.x;
-    info[at + 1] = (float)p.m.y;
-  }
-  info[ate] = __int_as_float(p.e);
-}
-__device__ __forceinline__ Prod get_prod(const float *info, int at, int at2, int ate) {
-  Prod p;
-  if (LONG) p.m = c2((Real) reinterpret_cast<const double *>(info + at2)[0], (Real) reinterpret_cast<const double *>(info + at2)[1]);
-  else p.m = c2((Real)info[at], (Real)info[at + 1]);
-  p.e = __float_as_int(info[ate]);
-  return p;
-}
-
 struct SharedR {
   union {
     struct {
@@ -503,21 +483,21 @@ __device__ __forceinline__ unsigned commit_ratio(const RowCfg &cfg, const float 
   return seen;
 }
 
-// MODE 0: one workgroup per row.  Few long rows (split_plan) are cut into S segments of seg_ch chunks, one workgroup
-// each, in two launches around bk_ratio_combine_kernel: the chunks of a row are independent except for the running
-// product, so MODE 1 computes only each segment's product (and its checks; no outputs), the combine kernel turns
-// those into the product entering each segment and checks the estimates across segment boundaries, and MODE 2 is
-// the full computation of each segment started from that product.
-// Per-segment record (floats): [0,1] product mantissa, [2] exponent, [3] a check failed, [4..7] right edge
-// (theta end value, phi warm-up of the last lane), [8..11] left edge (theta warm-up, phi end value of the first lane),
-// [12,13] mantissa and [14] exponent of the product entering the segment.
+// MODE 0: one workgroup per row.
 // MODE 3: more rows than the GPU holds workgroups at once: rows cut into S units of seg_ch chunks that hand the running
 // product and edge values on inside ONE launch (records and their tags: see RELAY_REC above); the same outputs as
 // MODE 0, bit for bit.
 // SAVE (MODE 0 only, for the analytic backward): also stores r_j and s_j, and writes G_raw (before the final
 // log-magnitude clamp and the clip; 0 outside 1e-18 <= |G_raw| <= 1e18) instead of G.
-template <typename TIn, bool PHI_EXACT, int MODE, bool SAVE = false>
-__global__ __launch_bounds__(RT, (MODE == 4 && (!LONG || BK_LOOK_LONG3)) ? BK_RATIO_WAVES : ((MODE == 0 || MODE == 3) && !SAVE && !LONG && sizeof(TIn) != 2) ? BK_RATIO_WAVES : 2) void bk_ratio_forward_kernel(
+// BST (float32 chains, MODE 0 / 4, for the analytic backward): also stores, for every block of BST_BLOCK = 8
+// elements m, the two values the ratio chains of that block start from -- om(r_{8m-1}), what the theta chain carries
+// into the block from the left, and om(s_{8m+9}), what the phi chain carries towards it from the right (one more step,
+// at element 8m+8, gives the backward the terms it needs of that element) -- as one record of two complex numbers in
+// save_r_ (16 bytes per 8 elements; record 0's first half is never written: the theta chain enters a row with 0).
+constexpr int BST_BLOCK = 8;
+static_assert(E == 2 * BST_BLOCK, "a lane's elements are two blocks of the analytic backward");
+template <typename TIn, bool PHI_EXACT, int MODE, bool SAVE = false, bool BST = false>
+__global__ __launch_bounds__(RT, BST ? 2 : (MODE == 4 && (!LONG || BK_LOOK_LONG3)) ? BK_RATIO_WAVES : ((MODE == 0 || MODE == 3) && !SAVE && !LONG && sizeof(TIn) != 2) ? BK_RATIO_WAVES : 2) void bk_ratio_forward_kernel(
     const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
     const float *__restrict__ z_dev, float z_re, float z_im, long B, long N_, float2 *__restrict__ G_,
     float2 *__restrict__ F_, char *__restrict__ ws, int *state, unsigned flags, float fclamp, int S,
@@ -565,7 +545,6 @@ __global__ __launch_bounds__(RT, (MODE == 4 && (!LONG || BK_LOOK_LONG3)) ? BK_RA
     sg = S - 1 - (int)(unit / (unsigned)B);
   }
   int *rowflag = reinterpret_cast<int *>(ws);
-  if (MODE == 2 && rowflag[row] != 0) return;  // the whole row is recomputed by the scan kernel
   // MODE 3 works in coordinates that start at the unit's first chunk (element index, row length and chunk numbers
   // all count from there; what lies to the left is reachable through `left_open`): the chunk loop then is the loop
   // of MODE 0, which is what fits the register budget of three workgroups per CU.
@@ -577,10 +556,13 @@ __global__ __launch_bounds__(RT, (MODE == 4 && (!LONG || BK_LOOK_LONG3)) ? BK_RA
   const TIn *c = N_ >= 2 ? c_ + row * ldc + shift : a;
   float2 *G = G_ + row * N_ + shift;
   float2 *F = F_ ? F_ + row * N_ + shift : nullptr;
+  // boundary states of the row (two complex numbers per block), in the unit's coordinates like everything else
+  float4 *bst = BST ? reinterpret_cast<float4 *>(save_r_) + row * ((N_ + BST_BLOCK - 1) / BST_BLOCK) + shift / BST_BLOCK
+                    : nullptr;
+  const long nblk = (N + BST_BLOCK - 1) / BST_BLOCK;  // blocks from the unit's first element to the end of the row
   const int nch = (int)((N + RCHUNK - 1) / RCHUNK);
-  const int ch0 = (MODE == 0 || RELAY) ? 0 : LOOK ? nch - 1 - sg : sg * seg_ch;
-  const int ch1 = MODE == 0 ? nch : LOOK ? ch0 + 1 : min(nch, ch0 + seg_ch);
-  float *info = reinterpret_cast<float *>(ws + rowflag_bytes(B) + lane_state_bytes(B, N_)) + (row * S + sg) * SEG_INFO;
+  const int ch0 = LOOK ? nch - 1 - sg : 0;
+  const int ch1 = LOOK ? ch0 + 1 : RELAY ? min(nch, seg_ch) : nch;  // (a unit: seg_ch chunks from its start)
   RowCfg cfg;
   cfg.z = z_dev ? make_float2(z_dev[0], z_dev[1]) : make_float2(z_re, z_im);
   cfg.N = N;
@@ -596,7 +578,7 @@ __global__ __launch_bounds__(RT, (MODE == 4 && (!LONG || BK_LOOK_LONG3)) ? BK_RA
   bool bad = false;
   int nscan = 0;
   if (t == 0) {
-    sh.carry[0] = MODE == 2 ? get_prod(info, 12, 20, 14) : prod_one();
+    sh.carry[0] = prod_one();
   }
   // BKCORE_FLAG_ADAPTIVE: the previous call recomputed most of its rows (state[7]) and this is not one of the calls
   // that try again (state[8] == 0): only read and stage the inputs (that is what finds the NaN verdicts the second
@@ -611,7 +593,9 @@ __global__ __launch_bounds__(RT, (MODE == 4 && (!LONG || BK_LOOK_LONG3)) ? BK_RA
   // (2 waves per SIMD).
   // 16-bit operands (the layer's bfloat16 diagonal) measured faster with two workgroups per CU and the prefetch:
   // twice the load instructions per byte
-  constexpr bool PREFETCH = !((MODE == 0 || MODE == 3) && !SAVE && BK_RATIO_WAVES >= 3 && sizeof(TIn) != 2) && !LONG && !LOOK && BK_RATIO_PREFETCH;
+  // (the variant that keeps the boundary states does not fit three workgroups per CU: anything more that lives across
+  // the chunk loop makes the compiler spill a hundred registers at that budget; it runs two per CU with the prefetch)
+  constexpr bool PREFETCH = !((MODE == 0 || MODE == 3) && !SAVE && !BST && BK_RATIO_WAVES >= 3 && sizeof(TIn) != 2) && !LONG && !LOOK && BK_RATIO_PREFETCH;
   float av[RNJ], bv[RNJ], cv[RNJ];
   auto prefetch = [&](int ch) __attribute__((always_inline)) {
     // `full`: the chunk and its halos (and the one extra k) lie inside the row
@@ -732,11 +716,15 @@ __global__ __launch_bounds__(RT, (MODE == 4 && (!LONG || BK_LOOK_LONG3)) ? BK_RA
     const float2 th_west = to_f2(wt), ph_west = to_f2(wp);
 
     BK_STAMP(4);
+    float2 bs_tmid = make_float2(0.f, 0.f), bs_p9 = bs_tmid, bs_p1 = bs_tmid;  // (BST) boundary states of the lane
     // theta over the lane's own elements, left -> right: keeps 1 / r_e
 #pragma unroll
     for (int j = 0; j < E; ++j) {
       wt = ratio_step(al_l[roff(j)], k_l[roff(j)], wt, r, inv, lmin);
       ir[j] = inv;
+      if constexpr (BST) {
+        if (j == BST_BLOCK - 1) bs_tmid = to_f2(wt);  // what enters the lane's second block
+      }
       BK_SCHED_FENCE(j);
     }
     const float2 th_fin = to_f2(wt);
@@ -752,6 +740,10 @@ __global__ __launch_bounds__(RT, (MODE == 4 && (!LONG || BK_LOOK_LONG3)) ? BK_RA
       const int e = E - 1 - j;
       wp = ratio_step_om(al_l[roff(e)], k_l[roff(e + KO)], wp, r, lmin);
       if (TAIL && i0 + e >= N) wp = c2((Real)0, (Real)0);
+      if constexpr (BST) {  // om(s) at the second element after the end of a block
+        if (e == BST_BLOCK + 1) bs_p9 = to_f2(wp);
+        if (e == 1) bs_p1 = to_f2(wp);
+      }
       const bool valid = !TAIL || i0 + e < N;
       const C2 loc = cmulr(ir[e], run.m);
       if (valid) run.m = cmulr(loc, r);
@@ -769,6 +761,29 @@ __global__ __launch_bounds__(RT, (MODE == 4 && (!LONG || BK_LOOK_LONG3)) ? BK_RA
     }
 #endif
     const float2 ph_fin = to_f2(wp);
+    if constexpr (BST) {
+      // the lane's elements are blocks m0 and m0 + 1: theta states enter blocks m0 + 1 and m0 + 2, phi states belong to
+      // blocks m0 - 1 (om(s) at the lane's element 1) and m0 (element 9); -1 is the last block of the unit to the left
+      const int m0 = (int)(i0 / BST_BLOCK);
+      const int nb = (int)nblk;
+      float *dst = reinterpret_cast<float *>(bst) + 4 * m0;
+      if (m0 + 1 < nb) {
+        __builtin_nontemporal_store(bs_tmid.x, dst + 4);
+        __builtin_nontemporal_store(bs_tmid.y, dst + 5);
+      }
+      if (m0 + 2 < nb) {
+        __builtin_nontemporal_store(th_fin.x, dst + 8);
+        __builtin_nontemporal_store(th_fin.y, dst + 9);
+      }
+      if (m0 < nb) {
+        __builtin_nontemporal_store(bs_p9.x, dst + 2);
+        __builtin_nontemporal_store(bs_p9.y, dst + 3);
+      }
+      if ((m0 >= 1 || left_open) && m0 - 1 < nb) {
+        __builtin_nontemporal_store(bs_p1.x, dst - 2);
+        __builtin_nontemporal_store(bs_p1.y, dst - 1);
+      }
+    }
 
     BK_STAMP(6);
     bad |= !(lmin >= WALL_LN_MIN);  // a ratio below 1e-2 in magnitude: outside the clamp factor's series
@@ -932,16 +947,7 @@ __global__ __launch_bounds__(RT, (MODE == 4 && (!LONG || BK_LOOK_LONG3)) ? BK_RA
         bad |= differs_tight(ph_west, make_float2(nb.z, nb.w));
       }
       if (t == RT - 1) sh.edge[buf] = make_float4(th_west.x, th_west.y, ph_fin.x, ph_fin.y);
-      if (MODE == 1) {  // the two ends of the segment are checked against its neighbours by the combine kernel
-        if (t == 0 && ch == ch1 - 1) {
-          info[4] = th_fin.x; info[5] = th_fin.y; info[6] = ph_west.x; info[7] = ph_west.y;
-        }
-        if (t == RT - 1 && ch == ch0) {
-          info[8] = th_west.x; info[9] = th_west.y; info[10] = ph_fin.x; info[11] = ph_fin.y;
-        }
-      }
     }
-    if (MODE == 1) return;  // only the product was wanted
     // (every wave finished reading the staged inputs before the barrier above: the tile may overwrite them)
 
     // epilogue (bk_core.py:190-208) into the output tile.  Lq = log2 |G_raw|^2; the final soft clamp multiplies by
@@ -1107,12 +1113,6 @@ __global__ __launch_bounds__(RT, (MODE == 4 && (!LONG || BK_LOOK_LONG3)) ? BK_RA
         __hip_atomic_fetch_or(&rowflag[row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&state[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-    } else if (MODE == 1) {
-      put_prod(info, 0, 16, 2, sh.carry[nscan & 1]);  // started from one: the segment's own product
-      info[3] = any_bad ? 1.0f : 0.0f;
-    } else if (any_bad) {
-      atomicOr(&rowflag[row], 1);
-      __hip_atomic_store(&state[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (seen) {
@@ -1133,60 +1133,6 @@ __global__ __launch_bounds__(RT, (MODE == 4 && (!LONG || BK_LOOK_LONG3)) ? BK_RA
   }  // units
 }
 
-// One wave per row, one lane per segment (64 at a time, right to left): the product entering each segment, the
-// checks across segment boundaries, the row's verdict.
-__global__ __launch_bounds__(64) void bk_ratio_combine_kernel(long B, long N, char *__restrict__ ws, int *state, int S) {
-  const long row = blockIdx.x;
-  const int lane = threadIdx.x;
-  int *rowflag = reinterpret_cast<int *>(ws);
-  float *info = reinterpret_cast<float *>(ws + rowflag_bytes(B) + lane_state_bytes(B, N)) + row * S * SEG_INFO;
-  bool bad = false;
-  Prod carry = prod_one();
-  for (int g0 = 0; g0 < S; g0 += 64) {
-    const int idx = g0 + lane;
-    const int sg = S - 1 - idx;  // ascending lanes = segments right to left
-    Prod q = prod_one();
-    if (idx < S) {
-      const float *me = info + sg * SEG_INFO;
-      q = get_prod(me, 0, 16, 2);
-      bad |= me[3] != 0.0f;
-      if (sg < S - 1) {
-        const float *rt = me + SEG_INFO;  // the segment to the right
-        bad |= differs_tight(make_float2(rt[8], rt[9]), make_float2(me[4], me[5]));
-        bad |= differs_tight(make_float2(me[6], me[7]), make_float2(rt[10], rt[11]));
-      }
-    }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      Prod o;
-      o.m.x = __shfl_up(q.m.x, d);
-      o.m.y = __shfl_up(q.m.y, d);
-      o.e = __shfl_up(q.e, d);
-      if (lane >= d) q = pmul(q, o);
-    }
-    Prod ex;
-    ex.m.x = __shfl_up(q.m.x, 1);
-    ex.m.y = __shfl_up(q.m.y, 1);
-    ex.e = __shfl_up(q.e, 1);
-    if (lane == 0) ex = prod_one();
-    ex = pmul(carry, ex);
-    if (idx < S) {
-      float *me = info + sg * SEG_INFO;
-      put_prod(me, 12, 20, 14, ex);
-    }
-    Prod last;
-    last.m.x = __shfl(q.m.x, 63);
-    last.m.y = __shfl(q.m.y, 63);
-    last.e = __shfl(q.e, 63);
-    carry = pmul(carry, last);
-  }
-  const int any_bad = __syncthreads_or(bad ? 1 : 0);
-  if (lane == 0) {
-    rowflag[row] = any_bad ? 1 : 0;
-    if (any_bad) __hip_atomic_store(&state[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
 }  // namespace
 
 namespace {
@@ -1195,14 +1141,24 @@ void ratio_launch(int mode, int save, const void *a, long lda, const void *b, lo
                   const float *z_dev, float z_re, float z_im, long B, long N, float *G, float *features, void *ws,
                   void *state, unsigned flags, float fclamp, int S, int seg_ch, float *save_r,
                   float *save_s, hipStream_t stream) {
-#define BK_RATIO(MODE, SAVE, GRID)                                                                                   \
-  hipLaunchKernelGGL((bk_ratio_forward_kernel<TIn, PHI_EXACT, MODE, SAVE>), dim3((unsigned)(GRID)), dim3(RT), 0,      \
+#define BK_RATIO(MODE, SAVE, GRID) BK_RATIO2(MODE, SAVE, false, GRID)
+#define BK_RATIO2(MODE, SAVE, BSTV, GRID)                                                                            \
+  hipLaunchKernelGGL((bk_ratio_forward_kernel<TIn, PHI_EXACT, MODE, SAVE, BSTV>), dim3((unsigned)(GRID)), dim3(RT), 0, \
                      stream, (const TIn *)a, lda, (const TIn *)b, ldb, (const TIn *)c, ldc, z_dev, z_re, z_im, B, N, \
                      (float2 *)G, (float2 *)features, (char *)ws, (int *)state, flags, fclamp, S, seg_ch,   \
                      (float2 *)save_r, (float2 *)save_s)
-  if (mode == 1) BK_RATIO(1, false, B * S);
-  else if (mode == 2) BK_RATIO(2, false, B * S);
-  else if (mode == 4) BK_RATIO(4, false, B * S);
+  // save_r given with mode 3 / 4, or save == 2 with mode 0: the variant that also stores the boundary states there
+  // (float32 operands, float32 chains)
+#if !BK_RATIO_LONG
+  if constexpr (std::is_same<TIn, float>::value) {
+    if (save_r != nullptr && (mode == 4 || (mode == 0 && save == 2))) {
+      if (mode == 4) BK_RATIO2(4, false, true, B * S);
+      else BK_RATIO2(0, false, true, B);
+      return;
+    }
+  }
+#endif
+  if (mode == 4) BK_RATIO(4, false, B * S);
 #if !BK_RATIO_LONG
   else if (mode == 3) BK_RATIO(3, false, (BK_RELAY_PERSIST && save > 0 && save < B * S) ? save : B * S);  // save: places
 #endif
@@ -1211,6 +1167,7 @@ void ratio_launch(int mode, int save, const void *a, long lda, const void *b, lo
   else if (std::is_same<TIn, float>::value) BK_RATIO(0, true, B);  // the saving variant exists for float32 operands
 #endif
 #undef BK_RATIO
+#undef BK_RATIO2
 }
 }  // namespace
 
@@ -1286,9 +1243,3 @@ extern "C" int bkcore_internal_ratio_unit_occupancy(int in_dtype, int phi_exact)
   return slot > 0 ? slot : 0;
 }
 #endif
-
-extern "C" void BK_RATIO_ENTRY(bkcore_internal_ratio_combine)(int64_t B, int64_t N, void *ws, void *state, int S,
-                                              void *stream) {
-  hipLaunchKernelGGL(bk_ratio_combine_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, (long)B, (long)N,
-                     (char *)ws, (int *)state, S);
-}

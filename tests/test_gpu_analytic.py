@@ -295,3 +295,81 @@ def test_argument_checks(bk):
     empty = bk.bk_backward_analytic(torch.zeros(0, 8, device="cuda"), torch.zeros(0, 7, device="cuda"),
                                     torch.zeros(0, 7, device="cuda"), 1j, None, None)
     assert empty[0].shape == (0, 8)
+
+
+@pytest.mark.parametrize("B,N,exact", [(3, 8, False), (2, 9, False), (2, 17, True), (3, 2031, False), (2, 2033, False),
+                                       (3, 4095, True), (2, 4097, False), (4, 6112, False), (130, 8197, False),
+                                       (5, 40000, False), (16, 65545, True), (2, 32768, False)])
+def test_backward_from_kept_boundary_states(bk, B, N, exact):
+    """The forward that also keeps what its ratio chains carry into every block of 8 elements
+    (bkcore_forward_states) and the backward that starts from it (bkcore_backward_analytic_states): same gradients as
+    the backward that warms its chains up again (to rounding), within tolerance of the float64 adjoint, no row sent
+    to the three-pass path; lengths around the backward's chunk geometry, one workgroup per row and per chunk."""
+    from bkcore import bk_core
+    z = 0.3 + 0.9j if exact else 1j
+    a, b, c, gf, _ = _case(B, N, 500 + N + B)
+    ad, bd, cd, gd = a.float().cuda(), b.float().cuda(), c.float().cuda(), gf.float().cuda()
+    bk_core._DEBUG["keep_ws"] = True
+    try:
+        _, G, st = bk.bk_forward(ad, bd, cd, z, raw=True, phi_exact=exact, want_states=True)
+        assert st is not None and tuple(st.shape) == (B, (N + 7) // 8, 4)
+        _, G0 = bk.bk_forward(ad, bd, cd, z, raw=True, phi_exact=exact)
+        assert float((G - G0).abs().max() / G0.abs().max()) <= 2e-6    # two instantiations of the same kernel
+        g_re = bk.bk_backward_analytic(ad, bd, cd, z, gd, None, phi_exact=exact, G=G)
+        g_st = bk.bk_backward_analytic(ad, bd, cd, z, gd, None, phi_exact=exact, G=G, states=st)
+        assert bk_core.analytic_rows_recomputed() == 0
+    finally:
+        bk_core._DEBUG["keep_ws"] = False
+    rows = sorted({0, B - 1})
+    gbar = (gf[rows, :, 0] + 1j * gf[rows, :, 1]).numpy()
+    ref = adjoint_grads(a[rows].numpy(), b[rows].numpy(), c[rows].numpy(), z, gbar, "exact" if exact else "reference")
+    for x, y, r in zip(g_st, g_re, ref[:3]):
+        assert rel(x[rows].cpu().numpy(), r) <= TOL
+        assert float((x - y).abs().max() / y.abs().max()) <= 2e-5
+
+
+def test_boundary_states_of_a_recomputed_row_are_not_trusted(bk):
+    """A row whose forward was recomputed on the two-scan path holds boundary states that do not belong to its G: the
+    backward's consistency checks send that row to the three-pass path; its neighbours are untouched."""
+    from bkcore import bk_core
+    B, N = 4, 9000
+    a, b, c, gf, _ = _case(B, N, 77)
+    a[2, 3000:3300] = 0.0
+    b[2, 3000:3300] = 3.0                                  # |k| / |r|^2 ~ 0.7: no contraction within the warm-up
+    c[2, 3000:3300] = 3.0
+    ad, bd, cd, gd = a.float().cuda(), b.float().cuda(), c.float().cuda(), gf.float().cuda()
+    bk_core._DEBUG["keep_ws"] = True
+    try:
+        _, G, st = bk.bk_forward(ad, bd, cd, 1j, raw=True, want_states=True)
+        assert bk_core.rows_recomputed() == 1
+        g_st = bk.bk_backward_analytic(ad, bd, cd, 1j, gd, None, G=G, states=st)
+        assert bk_core.analytic_rows_recomputed() == 1
+    finally:
+        bk_core._DEBUG["keep_ws"] = False
+    gbar = (gf[..., 0] + 1j * gf[..., 1]).numpy()
+    ref = adjoint_grads(a.numpy(), b.numpy(), c.numpy(), 1j, gbar, "reference")
+    for x, r in zip(g_st, ref[:3]):
+        assert rel(x.cpu().numpy(), r) <= TOL
+
+
+def test_autograd_keeping_boundary_states(bk):
+    """BKCoreFunction in analytic mode with KEEP_BOUNDARY_STATES: the same gradients as without (to rounding); rows
+    longer than 131072 elements and 16-bit operands fall back to the recomputing backward by themselves."""
+    bk.BKCoreFunction.GRAD_MODE = "analytic"
+    try:
+        for B, N, dt in ((3, 5000, torch.float32), (2, 140000, torch.float32), (2, 3000, torch.bfloat16)):
+            a, b, c, gf, _ = _case(B, N, 900 + N)
+            grads = {}
+            for keep in (False, True):
+                bk.BKCoreFunction.KEEP_BOUNDARY_STATES = keep
+                ar = a.to(dt).cuda().requires_grad_(True)
+                br = b.to(dt).cuda().requires_grad_(True)
+                cr = c.to(dt).cuda().requires_grad_(True)
+                feats, _ = bk.BKCoreFunction.apply(ar, br, cr, 1j)
+                (feats * gf.float().cuda()).sum().backward()
+                grads[keep] = [x.grad.float().clone() for x in (ar, br, cr)]
+            for x, y in zip(grads[True], grads[False]):
+                assert float((x - y).abs().max() / y.abs().max()) <= (2e-5 if dt == torch.float32 else 0.0)
+    finally:
+        bk.BKCoreFunction.KEEP_BOUNDARY_STATES = False
+        bk.BKCoreFunction.GRAD_MODE = "reference"

@@ -105,7 +105,7 @@ def test_hybrid_lm_step_at_phase7_small_batch(tmp_path):
         logits = m(tok.to(dev))
         loss = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), tgt.to(dev).reshape(-1))
         loss.backward()
-        res[dev] = (float(loss), {k: (None if p.grad is None else float(p.grad.double().norm()))
+        res[dev] = (float(loss.detach()), {k: (None if p.grad is None else float(p.grad.double().norm()))
                                   for k, p in m.named_parameters()})
     assert abs(res["cuda"][0] - res["cpu"][0]) <= 1e-4 * res["cpu"][0]
     seen_v = 0
