@@ -49,9 +49,9 @@ def _find(kernels, *parts):
 
 
 def test_headline_forward_fits_three_workgroups_per_cu(kernels):
-    # bk_ratio_forward_kernel<float, PHI_EXACT, MODE 0, SAVE false> of the float32 translation unit (the one for rows
-    # longer than 131072, with its chains in double, has the same names and a two-workgroup budget)
-    hits = _find(kernels, "bk_ratio_forward_kernelIfLb", "ELi0ELb0E")
+    # bk_ratio_forward_kernel<float, PHI_EXACT, MODE 0, SAVE false, BST false> of the float32 translation unit (the one
+    # for rows longer than 131072, with its chains in double, has the same names and a two-workgroup budget)
+    hits = _find(kernels, "bk_ratio_forward_kernelIfLb", "ELi0ELb0ELb0E")
     by_unit = {}
     for k in hits:
         by_unit.setdefault(k.split(":")[0], []).append(kernels[k])
@@ -65,12 +65,36 @@ def test_headline_forward_fits_three_workgroups_per_cu(kernels):
 def test_forward_in_units_keeps_the_same_budget(kernels):
     # bk_ratio_forward_kernel<float, PHI_EXACT, MODE 3, SAVE false>: rows cut into units of one launch run the chunk
     # loop of MODE 0; a formulation that keeps one more scalar alive across that loop spills 30-100 dwords
-    hits = _find(kernels, "bk_ratio_forward_kernelIfLb", "ELi3ELb0E")
+    hits = _find(kernels, "bk_ratio_forward_kernelIfLb", "ELi3ELb0ELb0E")
     assert len(hits) == 2, hits
     for k in hits:
         r = kernels[k]
         assert r["vgpr_count"] <= 168 and r["private_segment_fixed_size"] <= 16, (k, r)
         assert 3 * r["group_segment_fixed_size"] <= 160 * 1024, (k, r)
+
+
+def test_forward_in_chunks_keeps_the_same_budget(kernels):
+    # bk_ratio_forward_kernel<float, PHI_EXACT, MODE 4, SAVE false, BST false>: one workgroup per chunk with the
+    # look-back hand-over; three per CU with float32 chains, two per CU (256 registers) with double chains
+    hits = _find(kernels, "bk_ratio_forward_kernelIfLb", "ELi4ELb0ELb0E")
+    assert len(hits) == 4, hits
+    small = [k for k in hits if kernels[k]["vgpr_count"] <= 168]
+    assert len(small) == 2, hits
+    for k in hits:
+        r = kernels[k]
+        per_cu = 3 if k in small else 2
+        assert r["private_segment_fixed_size"] == 0, (k, r)
+        assert per_cu * r["group_segment_fixed_size"] <= 160 * 1024, (k, r)
+
+
+def test_forward_keeping_boundary_states_runs_two_per_cu(kernels):
+    # BST true: does not fit the three-per-CU budget (a hundred spilled registers there); two per CU, no real spilling
+    hits = _find(kernels, "bk_ratio_forward_kernelIfLb", "ELb0ELb1E")
+    assert len(hits) == 4, hits                                       # MODE 0 and 4, both phi conventions
+    for k in hits:
+        r = kernels[k]
+        assert r["vgpr_count"] <= 256 and r["private_segment_fixed_size"] <= 32, (k, r)
+        assert 2 * r["group_segment_fixed_size"] <= 160 * 1024, (k, r)
 
 
 def test_one_pass_analytic_backward_does_not_spill(kernels):
