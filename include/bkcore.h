@@ -52,6 +52,13 @@ extern "C" {
                                     * rows than the GPU holds workgroups at once but fewer than three times as many; the
                                     * flags force it for any row count.  Bit for bit the results of whole rows. */
 #define BKCORE_FLAG_ROW_UNITS_MANY 32u
+#define BKCORE_FLAG_WHOLE_ROWS 128u /* never take the form in which a grid of one workgroup per place on the GPU hands
+                                    * the running product on between the two units of a row (the library's choice when
+                                    * there are more rows than places): that form needs its whole grid resident at once,
+                                    * which kernels of other streams -- the collectives of a data-parallel backward --
+                                    * can prevent; a unit then waits up to 50 ms before the call falls back.  One
+                                    * workgroup per row instead (one per chunk for few long rows, whose hand-over only
+                                    * depends on workgroups that started earlier). */
 #define BKCORE_FLAG_ROW_UNITS_MUTE 64u /* diagnostics, with one of the two above: the units do not publish their records, so
                                     * every unit that waits for one gives up after 50 ms and the call's last launch
                                     * recomputes every row (exercises that recovery; same results within the tolerance) */

@@ -17,6 +17,7 @@ FLAG_ADAPTIVE = 8
 FLAG_ROW_UNITS = 16
 FLAG_ROW_UNITS_MANY = 32
 FLAG_ROW_UNITS_MUTE = 64
+FLAG_WHOLE_ROWS = 128
 STATE_BYTES = 64
 ABI_VERSION = 16
 EINVAL, ETOOLONG, ELAUNCH, EWORKSPACE, ETOOBIG = -1, -2, -3, -4, -5

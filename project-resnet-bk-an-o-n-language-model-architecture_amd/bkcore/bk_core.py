@@ -45,6 +45,20 @@ def _state_block(device: torch.device, stream: int) -> torch.Tensor:
     return blk
 
 
+def _whole_rows_only() -> bool:
+    """BKCoreFunction.ROW_UNITS: "auto" keeps the library's choice except in a process that is one rank of a
+    torch.distributed job -- there a collective of another stream (the gradient all-reduce of a data-parallel backward)
+    may hold compute units while the forward runs, and the form that cuts rows into units handing over inside one launch
+    needs its whole grid resident at once; "never" / "always" force the answer."""
+    mode = BKCoreFunction.ROW_UNITS
+    if mode == "never":
+        return True
+    if mode == "always":
+        return False
+    dist = torch.distributed
+    return bool(dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
 def _cached_workspace(cache: dict, device: torch.device, stream: int, need: int) -> torch.Tensor:
     """One buffer per (device, stream): calls on one stream execute in order, so it serves them all (every call on the
     stream shares it; it is written before it is read by each).  It only ever grows, and a buffer that a larger one
@@ -185,7 +199,8 @@ def bk_forward(a, b, c, z, raw: bool = False, phi_exact: bool = False, want_feat
         state = _state_block(dev, stream)
         flags = (_lib.FLAG_RAW if raw else 0) | (_lib.FLAG_PHI_EXACT if phi_exact else 0) \
             | (_lib.FLAG_SCAN_PATH if _DEBUG["scan_path"] else 0) \
-            | (_lib.FLAG_ADAPTIVE if BKCoreFunction.ADAPTIVE_PATH else 0) | _DEBUG["row_units"]
+            | (_lib.FLAG_ADAPTIVE if BKCoreFunction.ADAPTIVE_PATH else 0) | _DEBUG["row_units"] \
+            | (_lib.FLAG_WHOLE_ROWS if _whole_rows_only() else 0)
         ws, ws_bytes = _workspace(L, dev, stream, B, N)
         if _DEBUG["keep_ws"]:       # diagnostics read the workspace after the call: give this call its own
             ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
@@ -495,6 +510,9 @@ class BKCoreFunction(torch.autograd.Function):
                                     # 16th such call tries it again.  Which kernel computes a well-conditioned row then
                                     # depends on the calls before it (same numbers to the operator's tolerance, not
                                     # bit for bit), hence off by default
+    ROW_UNITS = "auto"              # "auto" | "never" | "always": rows in two units of one launch when there are more
+                                    # rows than the GPU holds workgroups at once ("auto": not inside a distributed job,
+                                    # see _whole_rows_only)
     KEEP_BOUNDARY_STATES = False    # GRAD_MODE "analytic", opt-in: the forward also keeps the values its ratio chains
                                     # carry into every block of 8 elements (2 bytes per element) and the backward starts
                                     # its chains from them instead of warming them up again.  Measured at B = 1024,

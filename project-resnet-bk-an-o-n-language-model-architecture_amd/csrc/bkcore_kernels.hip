@@ -1465,7 +1465,7 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
     const int per_cu = (!SAVE && N <= BKCORE_INTERNAL_LONG_ROW && !(flags & BKCORE_FLAG_ADAPTIVE))
                            ? bkcore_internal_ratio_unit_occupancy(dtype_tag<TIn>(), PHI_EXACT) : 0;
     // (the variant that keeps the boundary states holds fewer workgroups per CU and has no unit form: whole rows)
-    if (per_cu > 0 && !bstates) relay_plan(B, N, bkcore_internal_ratio_chunk(), per_cu, flags, RS, rseg);
+    if (per_cu > 0 && !bstates && !(flags & BKCORE_FLAG_WHOLE_ROWS)) relay_plan(B, N, bkcore_internal_ratio_chunk(), per_cu, flags, RS, rseg);
     if (RS > 1)
       fwd(dtype_tag<TIn>(), PHI_EXACT, 3, per_cu * device_cu_count(), a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
           flags, fclamp, RS, rseg, nullptr, nullptr, stream);
@@ -1830,6 +1830,7 @@ int bkcore_forward_plan(int64_t B, int64_t N, int in_dtype, unsigned flags, int 
   }
   if (launches) *launches = 2;
   if ((flags & (BKCORE_FLAG_SCAN_PATH | BKCORE_FLAG_ADAPTIVE)) || N > BKCORE_INTERNAL_LONG_ROW) return 1;
+  if (flags & BKCORE_FLAG_WHOLE_ROWS) return 1;
   int per_cu;
   if (cus > 0) {
     per_cu = (in_dtype == BKCORE_BF16 || in_dtype == BKCORE_F16) ? 2 : 3;

@@ -120,4 +120,6 @@ def test_forward_plan_policy():
     s, l = plan(16, 1 << 20, flags=_lib.FLAG_SCAN_PATH)
     assert s > 1 and l == 4                         # scan form: aggregates / combination / outputs / rows to recompute
     assert plan(100, 4 * 4096, flags=_lib.FLAG_ROW_UNITS) == (2, 2)
+    assert plan(1024, 32768, flags=_lib.FLAG_WHOLE_ROWS) == (1, 2)      # e.g. under data-parallel training
+    assert plan(16, 1 << 20, flags=_lib.FLAG_WHOLE_ROWS) == (256, 2)    # the chunk form does not need a resident grid
     assert L.bkcore_forward_plan(0, 5, _lib.F32, 0, 256, None) == _lib.EINVAL

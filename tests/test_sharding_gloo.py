@@ -28,6 +28,17 @@ def test_row_shard_tiles_the_batch():
         row_shard(8, 2, 2)
 
 
+def test_row_units_policy_outside_a_distributed_job():
+    from bkcore import bk_core
+    assert not dist.is_initialized()
+    assert not bk_core._whole_rows_only()
+    bk_core.BKCoreFunction.ROW_UNITS = "never"
+    try:
+        assert bk_core._whole_rows_only()
+    finally:
+        bk_core.BKCoreFunction.ROW_UNITS = "auto"
+
+
 def test_broadcast_operand_stays_a_view():
     b = torch.ones(1, 15).expand(8, -1)
     s = shard_rows(b, 2, 1)
@@ -54,6 +65,13 @@ def _worker(rank, world, port, B, N, out_dir):
         _, G_local = C.forward_f32(al.numpy(), bl.contiguous().numpy(), cl.contiguous().numpy(), 1j)
         G = gather_rows(torch.from_numpy(G_local), B)
         dist.barrier()
+        # inside a distributed job the operator keeps to whole rows: a collective on another stream may hold the
+        # compute units the form with units handing over inside one launch would need all at once
+        from bkcore import bk_core
+        assert bk_core._whole_rows_only()
+        bk_core.BKCoreFunction.ROW_UNITS = "always"
+        assert not bk_core._whole_rows_only()
+        bk_core.BKCoreFunction.ROW_UNITS = "auto"
         # the timing reduction bench.py uses: the slowest rank defines the step time
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
