@@ -168,6 +168,11 @@ def main():
         torch.cuda.set_device(device)
         import bkcore
         from bkcore import BKCoreFunction
+        # Inside a torch.distributed job the operator by itself keeps to one workgroup per row (a collective of another
+        # stream could hold compute units that the form with two units per row needs all at once).  Here no collective
+        # runs while the operator does -- the ranks only meet at the barriers around the timed region -- so every rank
+        # runs exactly what a single process runs.
+        BKCoreFunction.ROW_UNITS = "always"
         a, b, c, z, gfeat = make_inputs(B, N, device, 1234 + rank)
 
         def step():
