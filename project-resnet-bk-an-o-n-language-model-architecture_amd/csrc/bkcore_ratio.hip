@@ -190,7 +190,8 @@ struct SharedR {
 // memory left in the record cannot pass for a hand-off (a foreign value would have to equal a 64-bit hash of the
 // current epoch), and the reader of a record takes its tag down, so neither can what an earlier launch left.
 constexpr int RELAY_REC = 16;
-constexpr int ST_EPOCH = 9, ST_TICKET = 10, ST_REDO_ALL = 12;  // ints of the state block used by MODE 3 and 4
+constexpr int ST_EPOCH = 9, ST_REDO_ALL = 12;
+[[maybe_unused]] constexpr int ST_TICKET = 10;               // (BK_LOOK_TICKET builds only)  // ints of the state block used by MODE 3 and 4
 constexpr long long RELAY_WAIT_TICKS = 5000000;  // of the 100 MHz wall clock: 50 ms before a unit gives the launch up
 __device__ __forceinline__ unsigned long long relay_tag(int epoch, long unit) {
   unsigned long long x = ((unsigned long long)(unsigned)epoch << 32) ^ (unsigned long long)unit ^ 0x9E3779B97F4A7C15ull;
