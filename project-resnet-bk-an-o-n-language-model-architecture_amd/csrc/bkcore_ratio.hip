@@ -1055,7 +1055,31 @@ __global__ __launch_bounds__(RT, BST ? 2 : (MODE == 4 && (!LONG || BK_LOOK_LONG3
   }
 #endif
   // chunk kinds: those within reach of a halo of the end of the row (the last one or two), then the others
-  if (skip_arith) {  // uniform over the grid: stage every chunk for its NaN verdicts, nothing else
+  // (whole rows at three workgroups per CU only: the same few lines in the kernel for rows in units made the compiler
+  // spill 31 registers in its chunk loop)
+  if constexpr (MODE == 0 && !SAVE && !BST && !PREFETCH) {
+    int ch = ch1 - 1;
+    bool stage_only = skip_arith;
+    if (!skip_arith) {
+      for (; ch >= ch0 && (long)(ch + 1) * RCHUNK + RH + 1 > N; --ch) one(BoolC<true>{}, ch);
+      // A row whose chunks at the right end have failed their checks already is lost to the scan kernel whatever the
+      // rest does: it is only staged from here on (the NaN rules of the operator concern the whole batch, so every
+      // element still has to be looked at).  The decision depends on the row's own data alone.
+      if (ch >= ch0) stage_only = __syncthreads_or(bad ? 1 : 0) != 0;
+      if (!stage_only)
+        for (; ch >= ch0; --ch) one(BoolC<false>{}, ch);
+    }
+    if (stage_only) {  // uniform over the workgroup: stage the chunks for their NaN verdicts, nothing else
+#pragma unroll 1
+      for (; ch >= ch0; --ch) {
+        prefetch(ch);
+        __syncthreads();
+        seen |= commit_ratio(cfg, av, bv, cv, sh);
+        __syncthreads();
+      }
+      bad = true;
+    }
+  } else if (skip_arith) {  // uniform over the grid: stage every chunk for its NaN verdicts, nothing else
 #pragma unroll 1
     for (int ch = ch1 - 1; ch >= ch0; --ch) {
       prefetch(ch);
