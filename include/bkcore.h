@@ -53,12 +53,14 @@ extern "C" {
                                     * flags force it for any row count.  Bit for bit the results of whole rows. */
 #define BKCORE_FLAG_ROW_UNITS_MANY 32u
 #define BKCORE_FLAG_WHOLE_ROWS 128u /* never take the form in which a grid of one workgroup per place on the GPU hands
-                                    * the running product on between the two units of a row (the library's choice when
-                                    * there are more rows than places): that form needs its whole grid resident at once,
-                                    * which kernels of other streams -- the collectives of a data-parallel backward --
-                                    * can prevent; a unit then waits up to 50 ms before the call falls back.  One
-                                    * workgroup per row instead (one per chunk for few long rows, whose hand-over only
-                                    * depends on workgroups that started earlier). */
+                                    * the running product on between the two units of a row (the library's choice for
+                                    * float32 / float64 operands between 1.24 and 1.37 times as many rows as places):
+                                    * that form needs its whole grid resident at once, which kernels of other streams --
+                                    * the collectives of a data-parallel backward -- can prevent; a unit then waits up
+                                    * to 50 ms before the call falls back.  Rows go as one workgroup per chunk instead,
+                                    * whose hand-over only depends on workgroups that started earlier. */
+#define BKCORE_FLAG_ROWS_UNCUT 256u /* diagnostics: one workgroup per row whatever the shape (the form the others are
+                                    * checked against: units give its results bit for bit, chunks within 1e-5) */
 #define BKCORE_FLAG_ROW_UNITS_MUTE 64u /* diagnostics, with one of the two above: the units do not publish their records, so
                                     * every unit that waits for one gives up after 50 ms and the call's last launch
                                     * recomputes every row (exercises that recovery; same results within the tolerance) */
@@ -328,9 +330,12 @@ int64_t bkcore_max_seq_len(void);
 /* Diagnostics: how bkcore_forward would run a (B, N) problem of operand type in_dtype with `flags` and a state block.
  * cus <= 0: on the current device, with the workgroups per compute unit its runtime reports for the kernel (whole rows
  * if there is no device or no answer: exactly what the dispatch does); cus > 0: what-if for a GPU with that many
- * compute units holding 3 workgroups each (2 for 16-bit operands).  Returns pieces per row: 1 = one workgroup per row;
- * > 1 = rows cut into that many pieces that hand the running product over inside the first launch -- halves of rows
- * when there are more rows than the GPU holds workgroups at once, single chunks when there are few long rows.
+ * compute units holding 3 workgroups each (2 for 16-bit operands).  Returns pieces per row: 1 = one workgroup per row
+ * (rows that fill the GPU evenly: between 0.95 and 1 times as many rows as it holds workgroups, or more than 1.85
+ * times; rows of one or two chunks of 4096); the number of chunks of the row = one workgroup per chunk, the running
+ * product handed from chunk to chunk inside the launch (every other shape: fewer rows, or a ragged second round); 2 =
+ * two units a row on a grid that must be resident at once (float32 / float64 operands between 1.24 and 1.37 times as
+ * many rows as places, e.g. 1024 rows on 256 CUs; never with BKCORE_FLAG_WHOLE_ROWS).
  * *launches: 2 = that launch plus the (normally empty) launch for rows to recompute; 4 = few long rows in scan form
  * (BKCORE_FLAG_SCAN_PATH): piece aggregates / combination / piece outputs / rows to recompute.  No counterpart in the
  * reference. */

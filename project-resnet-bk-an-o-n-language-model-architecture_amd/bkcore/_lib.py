@@ -18,6 +18,7 @@ FLAG_ROW_UNITS = 16
 FLAG_ROW_UNITS_MANY = 32
 FLAG_ROW_UNITS_MUTE = 64
 FLAG_WHOLE_ROWS = 128
+FLAG_ROWS_UNCUT = 256      # diagnostics: one workgroup per row whatever the shape
 STATE_BYTES = 64
 ABI_VERSION = 16
 EINVAL, ETOOLONG, ELAUNCH, EWORKSPACE, ETOOBIG = -1, -2, -3, -4, -5

@@ -1393,6 +1393,57 @@ inline void relay_plan(int64_t B, int64_t N, int chunk, int wgs_per_cu, unsigned
   if (B * S > 2147483647LL) { S = 1; seg_ch = nch; }
 }
 
+// Which form the ratio-form first launch takes (state block given, no scan-path flag, nothing saved for the three-pass
+// backward).  Measured on MI355X (tools/ab_default_vs_chunks.sh; P = workgroups of the chunk kernel the GPU holds at
+// once, 3 per CU, 2 with the double-precision chains of long rows):
+//   whole rows   one workgroup per row.  Best when the rows fill the GPU evenly: B between 0.95 P and P, or B >= 1.85 P
+//                (a row's chunks cost 4-5 % more as workgroups of their own), and for rows of one or two chunks.
+//   chunks       one workgroup per chunk with the look-back hand-over (mode 4).  Best whenever whole rows would leave
+//                CUs unevenly or thinly occupied: B <= 0.95 P (129 rows x 32768: 0.064 -> 0.033 ms; 600 rows: 0.119 ->
+//                0.102 ms; 129 rows x 131072: 0.238 -> 0.090 ms) and P < B < 1.85 P (1300 rows: 0.205 -> 0.200 ms;
+//                16-bit operands, whose whole rows run two per CU: 0.236 -> 0.200 ms).
+//   units        rows in two units on a grid of one workgroup per place (mode 3): 4 % ahead of chunks between 1.24 P
+//                and 1.37 P for float32 / float64 operands (1024 rows: 0.155 against 0.162 ms) and nowhere else; needs
+//                its grid resident at once, so not with BKCORE_FLAG_WHOLE_ROWS.
+enum { FORM_WHOLE = 0, FORM_UNITS = 1, FORM_CHUNKS = 2 };
+inline int ratio_form_plan(int64_t B, int64_t N, int in_dtype, bool phi_exact, unsigned flags, bool keeps_states,
+                           int cus_given, int &S, int &seg_ch) {
+  const int chunk = bkcore_internal_ratio_chunk();
+  const int nch = (int)((N + chunk - 1) / chunk);
+  S = 1;
+  seg_ch = nch;
+  const bool long_rows = N > BKCORE_INTERNAL_LONG_ROW;
+  const bool sixteen = in_dtype == BKCORE_BF16 || in_dtype == BKCORE_F16;
+  // development: BKCORE_FORCE_CHUNKS=1 takes the chunk form wherever a row has two chunks, -1 never takes it
+  static const int force_chunks = [] { const char *e = getenv("BKCORE_FORCE_CHUNKS"); return e ? atoi(e) : 0; }();
+  const bool chunks_possible = nch >= 2 && B * (int64_t)nch <= 2000000000LL && force_chunks >= 0;
+  if (flags & BKCORE_FLAG_ROWS_UNCUT) return FORM_WHOLE;
+  if (flags & BKCORE_FLAG_ADAPTIVE)  // (its shortcut lives in the whole-row kernel)
+    return (chunks_possible && B <= 128 && nch >= 8) ? FORM_CHUNKS : FORM_WHOLE;
+  int per_cu = 0;  // of the unit kernel; 0: units not available
+  if (!long_rows && !keeps_states && !(flags & BKCORE_FLAG_WHOLE_ROWS)) {
+    if (cus_given > 0) per_cu = sixteen ? 2 : 3;
+    else per_cu = bkcore_internal_ratio_unit_occupancy(in_dtype, phi_exact);
+  }
+  static const int units_env = [] { const char *e = getenv("BKCORE_RELAY_UNITS"); return e ? atoi(e) : -1; }();
+  if (per_cu > 0 && ((flags & (BKCORE_FLAG_ROW_UNITS | BKCORE_FLAG_ROW_UNITS_MANY)) || units_env > 0)) {
+    relay_plan(B, N, chunk, per_cu, flags, S, seg_ch, cus_given);  // asked for by flag (diagnostics)
+    if (S > 1) return FORM_UNITS;
+  }
+  if (force_chunks > 0 && chunks_possible) return FORM_CHUNKS;
+  if (!chunks_possible) return FORM_WHOLE;
+  const int64_t P = (int64_t)(long_rows ? 2 : 3) * (cus_given > 0 ? cus_given : device_cu_count());
+  if (nch >= 3 && 20 * B <= 19 * P) return FORM_CHUNKS;
+  if (nch >= 4 && B > P && 20 * B < 37 * P) {
+    if (per_cu > 0 && !sixteen && 100 * B >= 124 * P && 100 * B <= 137 * P) {
+      relay_plan(B, N, chunk, per_cu, flags, S, seg_ch, cus_given);
+      if (S > 1) return FORM_UNITS;
+    }
+    return FORM_CHUNKS;
+  }
+  return FORM_WHOLE;
+}
+
 template <typename TIn>
 constexpr int dtype_tag() {
   return std::is_same<TIn, float>::value ? BKCORE_F32
@@ -1410,17 +1461,15 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
                      (const TIn *)a, (long)lda, (const TIn *)b, (long)ldb, (const TIn *)c, (long)ldc, z_dev, z_re,   \
                      z_im, (long)B, (long)N, (float2 *)G, (float2 *)features, (char *)ws, (int *)state,     \
                      SECOND, flags, fclamp, (float2 *)save_r, (float2 *)save_s)
-  int S = 1, seg_ch = 0;
-  if (state && !SAVE)
-    split_plan(B, N, (flags & BKCORE_FLAG_SCAN_PATH) ? CHUNK : bkcore_internal_ratio_chunk(), S, seg_ch);
-  // development: BKCORE_FORCE_CHUNKS=1 takes the one-workgroup-per-chunk form whatever the row count
-  static const int force_chunks = [] { const char *e = getenv("BKCORE_FORCE_CHUNKS"); return e ? atoi(e) : 0; }();
-  if (force_chunks && state && !SAVE && !(flags & (BKCORE_FLAG_SCAN_PATH | BKCORE_FLAG_ADAPTIVE)) &&
-      N >= 2 * bkcore_internal_ratio_chunk() && B * ((N + 4095) / 4096) < 2000000000LL)
-    S = 2;
-  if (S > 1 && !(flags & BKCORE_FLAG_SCAN_PATH)) {
-    // few long rows, ratio form: one workgroup per chunk, the running product handed from chunk to chunk inside the
-    // launch; then the (normally empty) launch of the scan kernel for rows whose checks failed
+  int S = 1, seg_ch = 0;         // scan form: segments per row
+  int form = FORM_WHOLE, RS = 1, rseg = 0;  // ratio form
+  if (state && !SAVE) {
+    if (flags & BKCORE_FLAG_SCAN_PATH) split_plan(B, N, CHUNK, S, seg_ch);
+    else form = ratio_form_plan(B, N, dtype_tag<TIn>(), PHI_EXACT, flags, bstates != nullptr, 0, RS, rseg);
+  }
+  if (form == FORM_CHUNKS) {
+    // ratio form, one workgroup per chunk, the running product handed from chunk to chunk inside the launch; then the
+    // (normally empty) launch of the scan kernel for rows whose checks failed
     const auto fwd = N > BKCORE_INTERNAL_LONG_ROW ? bkcore_internal_ratio_forward_long : bkcore_internal_ratio_forward;
     const int nch = (int)((N + bkcore_internal_ratio_chunk() - 1) / bkcore_internal_ratio_chunk());
     fwd(dtype_tag<TIn>(), PHI_EXACT, 4, 0, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
@@ -1459,13 +1508,10 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
     // single-sweep ratio-form first launch, then the (normally empty) second launch for rows whose checks failed
     const auto fwd = (N > BKCORE_INTERNAL_LONG_ROW && !SAVE) ? bkcore_internal_ratio_forward_long
                                                              : bkcore_internal_ratio_forward;
-    int RS = 1, rseg = 0;
-    // workgroups per CU: what the runtime says the kernel's registers and LDS allow on this device (the grid of the unit
-    // form must fit the GPU at once: its workgroups wait for each other); without an answer, whole rows
-    const int per_cu = (!SAVE && N <= BKCORE_INTERNAL_LONG_ROW && !(flags & BKCORE_FLAG_ADAPTIVE))
-                           ? bkcore_internal_ratio_unit_occupancy(dtype_tag<TIn>(), PHI_EXACT) : 0;
-    // (the variant that keeps the boundary states holds fewer workgroups per CU and has no unit form: whole rows)
-    if (per_cu > 0 && !bstates && !(flags & BKCORE_FLAG_WHOLE_ROWS)) relay_plan(B, N, bkcore_internal_ratio_chunk(), per_cu, flags, RS, rseg);
+    // units: the grid must fit the GPU at once (its workgroups wait for each other): workgroups per CU as the runtime
+    // reports them for this kernel on this device
+    const int per_cu = form == FORM_UNITS ? bkcore_internal_ratio_unit_occupancy(dtype_tag<TIn>(), PHI_EXACT) : 0;
+    if (form != FORM_UNITS || per_cu <= 0) RS = 1;
     if (RS > 1)
       fwd(dtype_tag<TIn>(), PHI_EXACT, 3, per_cu * device_cu_count(), a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
           flags, fclamp, RS, rseg, nullptr, nullptr, stream);
@@ -1819,32 +1865,22 @@ int bkcore_forward_plan(int64_t B, int64_t N, int in_dtype, unsigned flags, int 
   if (launches) *launches = 0;
   if (B <= 0 || N <= 0 || N > (int64_t)MAX_N || in_dtype < BKCORE_F32 || in_dtype > BKCORE_F64) return BKCORE_EINVAL;
   int S = 1, seg_ch = 0;
-  split_plan(B, N, (flags & BKCORE_FLAG_SCAN_PATH) ? CHUNK : bkcore_internal_ratio_chunk(), S, seg_ch);
-  if (S > 1) {
-    if (flags & BKCORE_FLAG_SCAN_PATH) {
-      if (launches) *launches = 4;
-      return S;
-    }
-    if (launches) *launches = 2;
-    return (int)((N + bkcore_internal_ratio_chunk() - 1) / bkcore_internal_ratio_chunk());  // one workgroup per chunk
+  if (flags & BKCORE_FLAG_SCAN_PATH) {
+    split_plan(B, N, CHUNK, S, seg_ch);
+    if (launches) *launches = S > 1 ? 4 : 2;
+    return S;
   }
   if (launches) *launches = 2;
-  if ((flags & (BKCORE_FLAG_SCAN_PATH | BKCORE_FLAG_ADAPTIVE)) || N > BKCORE_INTERNAL_LONG_ROW) return 1;
-  if (flags & BKCORE_FLAG_WHOLE_ROWS) return 1;
-  int per_cu;
-  if (cus > 0) {
-    per_cu = (in_dtype == BKCORE_BF16 || in_dtype == BKCORE_F16) ? 2 : 3;
-  } else {
-    int ndev = 0;  // as the dispatch: what the runtime reports for this kernel on the current device, whole rows without
+  if (cus <= 0) {  // as the dispatch: what the runtime reports on the current device; whole rows without one
+    int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
       (void)hipGetLastError();
       return 1;
     }
-    per_cu = bkcore_internal_ratio_unit_occupancy(in_dtype, (flags & BKCORE_FLAG_PHI_EXACT) != 0);
-    if (per_cu <= 0) return 1;
   }
-  relay_plan(B, N, bkcore_internal_ratio_chunk(), per_cu, flags, S, seg_ch, cus);
-  return S;
+  const int form = ratio_form_plan(B, N, in_dtype, (flags & BKCORE_FLAG_PHI_EXACT) != 0, flags, false, cus, S, seg_ch);
+  if (form == FORM_CHUNKS) return (int)((N + bkcore_internal_ratio_chunk() - 1) / bkcore_internal_ratio_chunk());
+  return form == FORM_UNITS ? S : 1;
 }
 int bkcore_last_hip_error(void) { return g_last_hip_error; }
 void bkcore_internal_set_hip_error(int code) { g_last_hip_error = code; }

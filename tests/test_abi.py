@@ -105,21 +105,26 @@ def test_forward_plan_policy():
         s = L.bkcore_forward_plan(B, N, dt, flags, 256, ctypes.byref(n))
         return s, n.value
 
-    assert plan(1024, 32768) == (2, 2)              # the headline shape: 1024 rows on 768 places, two pieces a row
-    assert plan(768, 32768) == (1, 2)               # one full round
-    assert plan(769, 32768) == (2, 2)
-    assert plan(1344, 32768) == (2, 2)              # last round three quarters full: still worth it
-    assert plan(1345, 32768) == (1, 2)
+    # pieces per row: 1 = whole rows, 2 = two units on a resident grid, chunks per row = one workgroup per chunk
+    assert plan(1024, 32768) == (2, 2)              # the headline shape: 1024 rows on 768 places, two units a row
+    assert plan(953, 32768) == (2, 2) and plan(1052, 32768) == (2, 2)    # ... the only band where units beat chunks
+    assert plan(952, 32768) == (8, 2) and plan(1053, 32768) == (8, 2)
+    assert plan(768, 32768) == (1, 2) and plan(730, 32768) == (1, 2)     # a full round of whole rows
+    assert plan(729, 32768) == (8, 2) and plan(129, 32768) == (8, 2)     # fewer rows: chunks fill the GPU evenly
+    assert plan(769, 32768) == (8, 2) and plan(1420, 32768) == (8, 2)    # a ragged second round: chunks
+    assert plan(1421, 32768) == (1, 2)
     assert plan(1536, 32768) == (1, 2) and plan(2000, 32768) == (1, 2) and plan(8192, 32768) == (1, 2)
-    assert plan(1024, 3 * 4096) == (1, 2)           # fewer than four chunks: nothing to cut
-    assert plan(1024, 32768, _lib.BF16) == (1, 2)   # 512 places: exactly two rounds
-    assert plan(600, 32768, _lib.BF16) == (2, 2)
+    assert plan(1024, 3 * 4096) == (1, 2)           # fewer than four chunks and more rows than places: whole rows
+    assert plan(600, 3 * 4096) == (3, 2) and plan(600, 2 * 4096) == (1, 2)
+    assert plan(1024, 32768, _lib.BF16) == (8, 2)   # 16-bit operands: chunks wherever units would be considered
+    assert plan(600, 32768, _lib.BF16) == (8, 2)
     assert plan(1024, 32768, flags=_lib.FLAG_ADAPTIVE) == (1, 2)
-    assert plan(1024, 1 << 18) == (1, 2)            # rows beyond 131072 elements run in double, whole
+    assert plan(1024, 1 << 18) == (1, 2)            # rows beyond 131072 elements run in double, two workgroups per CU
+    assert plan(600, 1 << 18) == (64, 2)
     assert plan(16, 1 << 20) == (256, 2)            # few long rows: one workgroup per chunk, handing over in the launch
     s, l = plan(16, 1 << 20, flags=_lib.FLAG_SCAN_PATH)
     assert s > 1 and l == 4                         # scan form: aggregates / combination / outputs / rows to recompute
     assert plan(100, 4 * 4096, flags=_lib.FLAG_ROW_UNITS) == (2, 2)
-    assert plan(1024, 32768, flags=_lib.FLAG_WHOLE_ROWS) == (1, 2)      # e.g. under data-parallel training
-    assert plan(16, 1 << 20, flags=_lib.FLAG_WHOLE_ROWS) == (256, 2)    # the chunk form does not need a resident grid
+    assert plan(1024, 32768, flags=_lib.FLAG_WHOLE_ROWS) == (8, 2)      # no resident grid (data-parallel training): chunks
+    assert plan(16, 1 << 20, flags=_lib.FLAG_WHOLE_ROWS) == (256, 2)
     assert L.bkcore_forward_plan(0, 5, _lib.F32, 0, 256, None) == _lib.EINVAL

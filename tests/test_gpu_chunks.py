@@ -225,3 +225,36 @@ def test_repeatable_under_other_work(bk):
     torch.cuda.synchronize()
     st = bk_core._state_block(a.device, torch.cuda.current_stream().cuda_stream).tolist()
     assert bad == 0 and st[12] == 0 and st[2] == 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_chunks_by_themselves_random_shapes(bk, seed):
+    """No flag: row counts at which whole rows would leave the GPU unevenly filled (fewer rows than 0.95 of its 768
+    places, or between one and 1.85 rounds of them outside the band where units are ahead), 3 to 9 chunks with ragged
+    ends, any operand type.  Parity with the oracle on a row subset, no row recomputed, the same bits on a second call,
+    and within 5e-5 of the same rows run as whole rows (the running product is put together in another order)."""
+    from bkcore import bk_core
+    from oracle import bk_oracle_c as C
+    rng = np.random.RandomState(3000 + seed)
+    B = int([rng.randint(129, 730), rng.randint(769, 953), rng.randint(1053, 1421)][seed % 3])
+    N = int(rng.randint(3 * CH - 50, 9 * CH)) if B < 730 else int(rng.randint(4 * CH - 50, 9 * CH))
+    if (N + CH - 1) // CH < (3 if B < 730 else 4):
+        N += CH
+    dtype = [torch.float32, torch.bfloat16, torch.float16, torch.float64][seed % 4]
+    a, b, c = _inputs(B, N, seed=4000 + seed, dtype=dtype, varying=bool(seed % 2))
+    z = complex(0.1 * seed, 0.8 + 0.1 * seed)
+    G, redone = _fresh(bk, a, b, c, z)
+    assert redone == 0
+    st = bk_core._state_block(a.device, torch.cuda.current_stream().cuda_stream).tolist()
+    assert st[9] > 0 and st[12] == 0           # a form with hand-overs ran and none was given up
+    G2, _ = _fresh(bk, a, b, c, z)
+    assert torch.equal(torch.view_as_real(G), torch.view_as_real(G2))
+    rows = sorted(set(rng.randint(0, B, size=6).tolist()) | {0, B - 1})
+    ref = C.get_diag(a[rows].double().cpu().numpy(), b[rows].double().cpu().numpy(), c[rows].double().cpu().numpy(), z)
+    assert max_rel_err(G[rows].cpu().numpy(), ref) <= TOL
+    bk_core._DEBUG["row_units"] = 256          # BKCORE_FLAG_ROWS_UNCUT
+    try:
+        Gw, _ = _fresh(bk, a, b, c, z)
+    finally:
+        bk_core._DEBUG["row_units"] = 0
+    assert max_rel_err(G.cpu().numpy(), Gw.cpu().numpy()) <= 5e-5

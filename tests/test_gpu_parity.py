@@ -234,9 +234,12 @@ def test_headline_size_properties(bk, coracle):
     Gref = coracle.get_diag(a[rows].cpu().numpy(), np.ones((len(rows), N - 1)), np.ones((len(rows), N - 1)), 1j)
     assert max_rel_err(G[rows].cpu().numpy(), Gref) <= TOL
     # a row computed inside another batch equals the same row computed inside this one (rows are independent systems):
-    # bitwise on the same code path, within tolerance when the row is computed alone (several workgroups per row)
+    # bitwise where the batch takes the same form (1000 rows: two units a row, like 1024), within tolerance where the
+    # running product is put together in another order (300 rows: one workgroup per chunk; one row alone likewise)
+    _, Gsub = bk.BKCoreFunction.apply(a[24:1024], b[24:1024], c[24:1024], z)
+    assert torch.equal(Gsub[753], G[777])
     _, Gsub = bk.BKCoreFunction.apply(a[600:900], b[600:900], c[600:900], z)
-    assert torch.equal(Gsub[177], G[777])
+    assert max_rel_err(Gsub[177].cpu().numpy(), G[777].cpu().numpy()) <= 5e-5
     _, Gone = bk.BKCoreFunction.apply(a[777:778], b[777:778], c[777:778], z)
     assert max_rel_err(Gone[0].cpu().numpy(), G[777].cpu().numpy()) <= 5e-5   # two evaluation orders, each ~1.5e-5 from the oracle
     # backward at the headline size: elementwise formula against the oracle's on the same rows

@@ -1,5 +1,5 @@
 """Rows cut into units that hand the running product on inside the first launch (BKCORE_FLAG_ROW_UNITS; taken by the
-library itself when there are more rows than the GPU holds workgroups at once).  Every chunk is computed by the same
+library itself for float32 / float64 operands in a band of row counts a little above what the GPU holds at once).  Every chunk is computed by the same
 code from the same numbers whichever workgroup runs it, so the results must equal those of whole rows bit for bit --
 on every path of the operator: ragged lengths, 16-bit and float64 operands, the reference's NaN rules
 (bk_core.py:256-264), rows whose checks fail and are recomputed, graph replay."""
@@ -10,6 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 CH = 4096  # elements per chunk of the ratio-form kernel
+UNCUT = 256  # BKCORE_FLAG_ROWS_UNCUT
 
 
 @pytest.fixture()
@@ -26,7 +27,7 @@ def bk():
 
 def _both(bk, units_flag, *args, **kw):
     from bkcore import bk_core, _lib
-    bk_core._DEBUG["row_units"] = 0
+    bk_core._DEBUG["row_units"] = UNCUT           # one workgroup per row whatever the shape
     f0, G0 = bk.bk_forward(*args, **kw)
     r0 = bk_core.rows_recomputed()
     bk_core._DEBUG["row_units"] = units_flag
@@ -100,9 +101,11 @@ def test_units_more_rows_than_places(bk):
     rows = [0, 1, 255, 256, 767, 768, 1023]
     ref = C.forward_f32(a[rows].cpu().numpy(), b[rows].cpu().numpy(), c[rows].cpu().numpy(), 1j)[1]
     assert float(np.max(np.abs(G[rows].cpu().numpy() - ref) / np.abs(ref))) <= 1e-4
-    # and a batch of some of the same rows that runs as whole rows (fewer rows than places, more than 128): bit for bit
+    # and a batch of some of the same rows run as whole rows: bit for bit
     rows = list(range(0, B, 5))
+    bk_core._DEBUG["row_units"] = UNCUT
     _, Gs = bk.bk_forward(a[rows].contiguous(), b[rows].contiguous(), c[rows].contiguous(), z)
+    bk_core._DEBUG["row_units"] = 0
     assert torch.equal(torch.view_as_real(Gs), torch.view_as_real(G[rows]))
 
 
@@ -176,10 +179,11 @@ def test_units_graph_replay(bk, own_state):
         graph.replay()
         torch.cuda.synchronize()
         outs.append((a.clone(), Gg.clone()))
-    bk_core._DEBUG["row_units"] = 0
+    bk_core._DEBUG["row_units"] = UNCUT
     for a_k, G_k in outs:
         _, G_e = bk.bk_forward(a_k, b, c, z)
         assert torch.equal(torch.view_as_real(G_e), torch.view_as_real(G_k))
+    bk_core._DEBUG["row_units"] = 0
 
 
 def test_units_give_up_and_recover(bk):
@@ -220,19 +224,26 @@ def test_units_give_up_and_recover(bk):
 
 @pytest.mark.parametrize("seed", range(6))
 def test_units_by_themselves_random_shapes(bk, seed):
-    """No flag: row counts between one and two rounds of workgroups, lengths of 4 to 9 chunks with ragged ends, any
-    operand type.  Rows in units against the same rows in a batch small enough to run as whole rows: bit for bit."""
+    """No flag: row counts in the band where the library takes units by itself (1.24 to 1.37 times the 768 places of an
+    MI355X), lengths of 4 to 9 chunks with ragged ends, float32 or float64 operands.  Rows in units against the same
+    rows run as whole rows: bit for bit."""
     from bkcore import bk_core
     rng = np.random.RandomState(1000 + seed)
-    B = int(rng.randint(769, 1300))
+    B = int(rng.randint(953, 1053))
     N = int(rng.randint(4 * CH - 50, 9 * CH))
-    dtype = [torch.float32, torch.float32, torch.bfloat16, torch.float16][seed % 4]
+    dtype = [torch.float32, torch.float32, torch.float64][seed % 3]
     a, b, c = _inputs(B, N, seed=2000 + seed, dtype=dtype, varying=bool(seed % 2))
     z = complex(0.1 * seed, 0.8 + 0.1 * seed)
     _, G = bk.bk_forward(a, b, c, z, want_features=False)
     assert bk_core.rows_recomputed() == 0
+    torch.cuda.synchronize()
+    if N > 4 * CH - 4096 + 1 and (N + CH - 1) // CH >= 4:
+        st = bk_core._state_block(a.device, torch.cuda.current_stream().cuda_stream).tolist()
+        assert st[9] > 0                       # a form with hand-overs ran (its epoch moved on)
     rows = sorted(set(rng.randint(0, B, size=200).tolist()) | {0, B - 1})
+    bk_core._DEBUG["row_units"] = UNCUT
     _, Gs = bk.bk_forward(a[rows].contiguous(), b[rows].contiguous(), c[rows].contiguous(), z, want_features=False)
+    bk_core._DEBUG["row_units"] = 0
     assert torch.equal(torch.view_as_real(Gs), torch.view_as_real(G[rows]))
 
 
