@@ -1125,14 +1125,18 @@ __global__ void bk_adjoint_finish(int *state) {
 
 extern "C" {
 
-// Segments per row for bk_adjoint_sweeps: rows are cut only when there are too few of them to occupy the chip
+// Segments per row for bk_adjoint_sweeps: rows are cut when there are too few of them to fill the GPU (two workgroups
+// per CU).  Measured on MI355X at N = 32768 (one workgroup per row -> segments): 8 rows 0.090 -> 0.039 ms, 64 rows
+// 0.114 -> 0.056 ms, 128 rows 0.119 -> 0.082 ms, 256 rows 0.162 -> 0.143 ms; from 384 rows on whole rows are ahead (the
+// segments' pre-pass reads G and the cotangent once more).
 static void sweep_plan(int64_t B, int64_t N, int &S, long &seg_len) {
   S = 1;
   seg_len = 0;
   const long chunks = (long)((N + STRIDE - 1) / STRIDE);
-  if (B > 128 || chunks < 16) return;
+  constexpr long ROWS_MAX = 256, MIN_CHUNKS = 2;   // chunks per segment at least
+  if (B > ROWS_MAX || chunks < 2 * MIN_CHUNKS) return;
   long want = (1024 + B - 1) / B;
-  if (want > chunks / 8) want = chunks / 8;     // at least eight chunks per segment
+  if (want > chunks / MIN_CHUNKS) want = chunks / MIN_CHUNKS;
   if (want > SWEEP_MAX_SEGMENTS) want = SWEEP_MAX_SEGMENTS;
   if (want < 2) return;
   // m chunks per segment: the first one of a later segment starts two lanes early, so m chunks cover m * STRIDE
