@@ -108,6 +108,14 @@ static_assert(RT % 64 == 0 && RT >= 64 && RT <= 256, "whole waves, at most the s
 #ifndef BK_LOOK_NOWAIT
 #define BK_LOOK_NOWAIT 0      // development: the chunks of MODE 4 do not wait for each other (wrong results; timing only)
 #endif
+#ifndef BK_PRIO
+// Wave priority by phase: raised from the start of a chunk to the barrier behind its staging (the part of a chunk
+// that three other waves wait for), normal in chains, epilogue and stores.  Measured at B = 1024, N = 32768: forward
+// 0.1535 -> 0.1520 ms, forward + backward 0.2650 -> 0.2610 ms; with the double-precision chains of long rows 1-2 %
+// slower, so not there.  (Development: 1 = only while the loads are issued, 3 = chains and epilogue instead,
+// 4 = 2 and the stores, 5 = staging only: all equal to or slower than 2.)
+#define BK_PRIO (BK_RATIO_LONG ? 0 : 2)
+#endif
 #ifndef BK_COMMIT_SUMS
 #define BK_COMMIT_SUMS 1
 #endif
@@ -653,12 +661,30 @@ __global__ __launch_bounds__(RT, BST ? 2 : (MODE == 4 && (!LONG || BK_LOOK_LONG3
     const long base = (long)ch * RCHUNK;
 
     BK_STAMP(0);
+#if BK_PRIO == 1 || BK_PRIO == 2 || BK_PRIO == 4
+    __builtin_amdgcn_s_setprio(3);
+#endif
+#if BK_PRIO == 6
+    __builtin_amdgcn_s_setprio(1);
+#endif
     if (!PREFETCH) prefetch(ch);  // no software pipelining: the other workgroups of the CU cover the latency
+#if BK_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __syncthreads();  // previous chunk's output tile has been stored
+#if BK_PRIO == 5
+    __builtin_amdgcn_s_setprio(3);
+#endif
     BK_STAMP(1);
     seen |= commit_ratio(cfg, av, bv, cv, sh);
     BK_STAMP(2);
     __syncthreads();
+#if BK_PRIO == 2 || BK_PRIO == 4 || BK_PRIO == 5 || BK_PRIO == 6
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#if BK_PRIO == 3
+    __builtin_amdgcn_s_setprio(3);
+#endif
     BK_STAMP(3);
     if (PREFETCH && ch > ch0) prefetch(ch - 1);  // in flight during this chunk's arithmetic
 
@@ -1003,7 +1029,13 @@ __global__ __launch_bounds__(RT, BST ? 2 : (MODE == 4 && (!LONG || BK_LOOK_LONG3
       }
     }
     BK_STAMP(9);
+#if BK_PRIO == 3
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __syncthreads();
+#if BK_PRIO == 4
+    __builtin_amdgcn_s_setprio(3);
+#endif
     BK_STAMP(10);
     float2 *__restrict__ Gc = G + base;
     float2 *__restrict__ Fc = F ? F + base : nullptr;
