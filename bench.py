@@ -369,7 +369,13 @@ def secondary_measurements(torch, bkcore, device, B, N, ad, b, c, z, gfeat, time
         t_ana_a = timed(lambda: bkcore.bk_backward_analytic(ad, b, c, z, gfeat, None, want_bc=False, G=Gs), 10)
         t_fwd_now = timed(lambda: bkcore.bk_forward(ad, b, c, z, share_storage=share), 10)
         t_fwd_two = timed(lambda: bkcore.bk_forward(ad, b, c, z, share_storage=False), 10)
-        del Gs
+        # ... and with the values the forward's ratio chains carry into every block of 8 elements kept for the backward
+        # (BKCoreFunction.KEEP_BOUNDARY_STATES, the default of analytic mode): 2 more bytes per element on either side
+        _, Gk, stk = bkcore.bk_forward(ad, b, c, z, share_storage=share, want_states=True)
+        t_fwd_keep = timed(lambda: bkcore.bk_forward(ad, b, c, z, share_storage=share, want_states=True), 10)
+        t_ana_keep = timed(lambda: bkcore.bk_backward_analytic(ad, b, c, z, gfeat, None, G=Gk, states=stk), 10) \
+            if stk is not None else None
+        del Gs, Gk, stk
         elems = float(B) * float(N)
         tr = None
         try:
@@ -387,6 +393,11 @@ def secondary_measurements(torch, bkcore, device, B, N, ad, b, c, z, gfeat, time
             "fwd_plus_analytic_bwd": {
                 "bytes_per_elem": FWD_BYTES + ANA_BYTES, "ms": (t_fwd_now + t_ana) * 1e3,
                 "frac": (FWD_BYTES + ANA_BYTES) * elems / (t_fwd_now + t_ana) / HBM_PEAK},
+            "from_kept_states": None if t_ana_keep is None else {
+                "fwd_ms": t_fwd_keep * 1e3, "bwd_ms": t_ana_keep * 1e3, "bytes_per_elem": FWD_BYTES + ANA_BYTES + 4.0,
+                "ms": (t_fwd_keep + t_ana_keep) * 1e3,
+                "frac": (FWD_BYTES + ANA_BYTES + 4.0) * elems / (t_fwd_keep + t_ana_keep) / HBM_PEAK,
+                "bwd_frac": (ANA_BYTES + 2.0) * elems / t_ana_keep / HBM_PEAK},
             "fwd_two_outputs_plus_analytic_bwd": {
                 "bytes_per_elem": FWD_BYTES_TWO + ANA_BYTES, "ms": (t_fwd_two + t_ana) * 1e3,
                 "frac": (FWD_BYTES_TWO + ANA_BYTES) * elems / (t_fwd_two + t_ana) / HBM_PEAK}}

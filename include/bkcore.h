@@ -181,30 +181,35 @@ size_t bkcore_backward_analytic_workspace_bytes(int64_t B, int64_t N);
  * The reference's forward saves nothing but G (src/models/bk_core.py:293) and its backward is elementwise; these two
  * have no counterpart there -- they are how "the analytic backward reuses the forward's scan states" is done here.
  *
- * bkcore_forward_states = bkcore_forward_clamped that also writes, for every block of 8 consecutive elements of every
- * row, the two values the ratio recurrences of that block start from (theta: entering from the left; phi: two elements
- * past the block, coming from the right): 16 bytes per 8 elements, bkcore_boundary_state_bytes(B, N) in all, into
- * boundary_states (device memory, 16-byte aligned).  *states_written (host int, may be NULL) says whether this call's
+ * bkcore_forward_states = bkcore_forward_clamped that also writes, for every block of 16 consecutive elements of every
+ * row, the two values its ratio recurrences end on at the block's borders (theta: what enters the block from the left;
+ * phi: the value at the block's second element, one step short of what enters the block to its left): 16 bytes per 16
+ * elements, rows padded to whole chunks of 4096 plus one block -- bkcore_boundary_state_bytes(B, N) in all -- into
+ * boundary_states (device memory, 16-byte aligned, boundary_state_bytes long: BKCORE_EWORKSPACE if that is less than
+ * bkcore_boundary_state_bytes(B, N)).  *states_written (host int, may be NULL) says whether this call's
  * path wrote them: yes for float32 operands with a state block, rows of at most 131072 elements and none of
  * BKCORE_FLAG_SCAN_PATH / BKCORE_FLAG_ADAPTIVE; otherwise the call is bkcore_forward_clamped and the backward has to
  * be given NULL.  boundary_states == NULL: plain bkcore_forward_clamped.
  *
  * bkcore_backward_analytic_states = bkcore_backward_analytic with boundary_states from the forward call that produced
- * G for the same operands and flags (G is then required): each lane starts its ratio chains from the kept values
- * instead of a 16-step warm-up on either side.  Rows whose forward was recomputed on the two-scan path hold states that
+ * G for the same operands and flags (G is then required): each lane reaches the start of its ratio chains from the
+ * kept values by eight exact steps of one of the two recurrences instead of a 16-step warm-up of both.  Rows whose
+ * forward was recomputed on the two-scan path hold states that
  * do not belong to their G; the lanes' consistency checks catch that and the row takes the three-pass path, as any row
  * failing its checks does.  boundary_states == NULL: bkcore_backward_analytic.
  */
 size_t bkcore_boundary_state_bytes(int64_t B, int64_t N);
 int bkcore_forward_states(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc,
                           int in_dtype, const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G,
-                          float *features, float feature_clamp, float *boundary_states, int *states_written,
-                          void *workspace, size_t workspace_bytes, void *state, unsigned flags, void *stream);
+                          float *features, float feature_clamp, float *boundary_states, size_t boundary_state_bytes,
+                          int *states_written, void *workspace, size_t workspace_bytes, void *state, unsigned flags,
+                          void *stream);
 int bkcore_backward_analytic_states(const float *a, int64_t lda, const float *b, int64_t ldb, const float *c,
                                     int64_t ldc, const float *z_dev, float z_re, float z_im, int64_t B, int64_t N,
-                                    const float *G, const float *boundary_states, const float *grad_features,
-                                    const float *grad_G, float *grad_a, float *grad_b, float *grad_c, void *workspace,
-                                    size_t workspace_bytes, void *state, unsigned flags, void *stream);
+                                    const float *G, const float *boundary_states, size_t boundary_state_bytes,
+                                    const float *grad_features, const float *grad_G, float *grad_a, float *grad_b,
+                                    float *grad_c, void *workspace, size_t workspace_bytes, void *state, unsigned flags,
+                                    void *stream);
 /* Diagnostics: byte offset, inside the workspace of bkcore_backward_analytic(B, N), of B ints that are non-zero after
  * the call for the rows the three-pass path recomputed (valid when state was given).  No counterpart in the reference. */
 size_t bkcore_backward_analytic_rowflag_offset(int64_t B, int64_t N);

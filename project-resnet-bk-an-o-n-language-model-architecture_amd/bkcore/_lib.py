@@ -20,7 +20,7 @@ FLAG_ROW_UNITS_MUTE = 64
 FLAG_WHOLE_ROWS = 128
 FLAG_ROWS_UNCUT = 256      # diagnostics: one workgroup per row whatever the shape
 STATE_BYTES = 64
-ABI_VERSION = 16
+ABI_VERSION = 17
 EINVAL, ETOOLONG, ELAUNCH, EWORKSPACE, ETOOBIG = -1, -2, -3, -4, -5
 BWD_REFERENCE, BWD_BATCHED, BWD_SCAN_STABLE = 0, 1, 2
 NOALLOC_MAX_WORKSPACE = 8 << 20
@@ -66,11 +66,13 @@ def load():
     L.bkcore_backward_analytic.argtypes = [vp, i64, vp, i64, vp, i64, vp, f32, f32, i64, i64, vp, vp, vp, vp, vp, vp,
                                            vp, ctypes.c_size_t, vp, ctypes.c_uint, vp]
     L.bkcore_backward_analytic.restype = i32
-    L.bkcore_backward_analytic_states.argtypes = [vp, i64, vp, i64, vp, i64, vp, f32, f32, i64, i64, vp, vp, vp, vp, vp,
-                                                  vp, vp, vp, ctypes.c_size_t, vp, ctypes.c_uint, vp]
+    L.bkcore_backward_analytic_states.argtypes = [vp, i64, vp, i64, vp, i64, vp, f32, f32, i64, i64, vp, vp,
+                                                  ctypes.c_size_t, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp,
+                                                  ctypes.c_uint, vp]
     L.bkcore_backward_analytic_states.restype = i32
     L.bkcore_forward_states.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp, f32, f32, i64, i64, vp, vp, f32, vp,
-                                        ctypes.POINTER(ctypes.c_int), vp, ctypes.c_size_t, vp, ctypes.c_uint, vp]
+                                        ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), vp, ctypes.c_size_t, vp,
+                                        ctypes.c_uint, vp]
     L.bkcore_forward_states.restype = i32
     L.bkcore_boundary_state_bytes.argtypes = [i64, i64]
     L.bkcore_boundary_state_bytes.restype = ctypes.c_size_t

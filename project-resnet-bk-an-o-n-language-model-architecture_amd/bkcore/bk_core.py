@@ -210,11 +210,12 @@ def bk_forward(a, b, c, z, raw: bool = False, phi_exact: bool = False, want_feat
             if not fc > 0.0:
                 raise ValueError("bkcore: feature_clamp must be positive")
         if want_states and dt == _lib.F32:
-            states = torch.empty((B, (N + 7) // 8, 4), dtype=torch.float32, device=dev)
+            st_bytes = int(L.bkcore_boundary_state_bytes(B, N))   # one float4 per block of 16, rows padded
+            states = torch.empty((B, st_bytes // (16 * B), 4), dtype=torch.float32, device=dev)
             written = ctypes.c_int(0)
             rc = L.bkcore_forward_states(pa, lda, pb if nb else None, ldb, pc if nb else None, ldc, dt, pz, zre, zim,
                                          B, N, G.data_ptr(), feats.data_ptr() if feats is not None else None, fc,
-                                         states.data_ptr(), ctypes.byref(written), ws.data_ptr(), ws_bytes,
+                                         states.data_ptr(), st_bytes, ctypes.byref(written), ws.data_ptr(), ws_bytes,
                                          state.data_ptr(), flags, stream)
             if not written.value:
                 states = None
@@ -433,9 +434,10 @@ def bk_backward_analytic(a, b, c, z, grad_features, grad_G, phi_exact: bool = Fa
     if states is not None:
         if gsaved is None:
             raise ValueError("bkcore: boundary states come with the G of the same forward call")
-        if states.dtype != torch.float32 or tuple(states.shape) != (B, (N + 7) // 8, 4) or states.device != a.device \
+        want = (B, int(L.bkcore_boundary_state_bytes(B, N)) // (16 * B), 4)
+        if states.dtype != torch.float32 or tuple(states.shape) != want or states.device != a.device \
                 or not states.is_contiguous():
-            raise ValueError("bkcore: states must be the (B, ceil(N/8), 4) float32 tensor the forward returned")
+            raise ValueError(f"bkcore: states must be the {want} float32 tensor the forward returned")
     with _on_device(a.device):
         stream = torch.cuda.current_stream().cuda_stream
         zkeep, pz, zre, zim = _prep_z(z, a.device)
@@ -451,6 +453,7 @@ def bk_backward_analytic(a, b, c, z, grad_features, grad_G, phi_exact: bool = Fa
         rc = L.bkcore_backward_analytic_states(pa, lda, pb if nb else None, ldb, pc if nb else None, ldc, pz, zre, zim, B, N,
                                         gsaved.data_ptr() if gsaved is not None else None,
                                         states.data_ptr() if states is not None else None,
+                                        states.numel() * 4 if states is not None else 0,
                                         gf.data_ptr() if gf is not None else None,
                                         gg.data_ptr() if gg is not None else None, ga.data_ptr(),
                                         gb.data_ptr() if gb is not None and nb else None,
@@ -513,12 +516,11 @@ class BKCoreFunction(torch.autograd.Function):
     ROW_UNITS = "auto"              # "auto" | "never" | "always": rows in two units of one launch when there are more
                                     # rows than the GPU holds workgroups at once ("auto": not inside a distributed job,
                                     # see _whole_rows_only)
-    KEEP_BOUNDARY_STATES = False    # GRAD_MODE "analytic", opt-in: the forward also keeps the values its ratio chains
-                                    # carry into every block of 8 elements (2 bytes per element) and the backward starts
-                                    # its chains from them instead of warming them up again.  Measured at B = 1024,
-                                    # N = 32768: backward 0.381 -> 0.342 ms, but the forward that keeps them fits two
-                                    # workgroups per CU instead of three and takes 0.217 instead of 0.154 ms -- it pays
-                                    # only when a forward is followed by more than one backward pass
+    KEEP_BOUNDARY_STATES = True     # GRAD_MODE "analytic": the forward also keeps the values its ratio chains carry
+                                    # into every block of 8 elements (2 bytes per element, held until the backward)
+                                    # and the backward starts its chains from them instead of warming them up again.
+                                    # Measured at B = 1024, N = 32768: forward 0.150 -> 0.165 ms, backward 0.361 ->
+                                    # 0.325 ms, together 0.511 -> 0.490 ms.  False: nothing but G is kept
     SHARE_FEATURES_STORAGE = True   # features = the float32 view of G_ii (same numbers, bk_core.py:296-298) instead of
                                     # a second tensor: halves the bytes the forward writes.  An in-place modification
                                     # of either output then raises in autograd; False gives two separate tensors
@@ -530,7 +532,8 @@ class BKCoreFunction(torch.autograd.Function):
         a2 = he_diag.reshape(-1, n) if he_diag.dim() != 2 else he_diag
         b2 = h0_super.reshape(-1, max(n - 1, 0)) if h0_super.dim() != 2 else h0_super
         c2 = h0_sub.reshape(-1, max(n - 1, 0)) if h0_sub.dim() != 2 else h0_sub
-        keep = BKCoreFunction.GRAD_MODE == "analytic" and BKCoreFunction.KEEP_BOUNDARY_STATES
+        keep = (BKCoreFunction.GRAD_MODE == "analytic" and BKCoreFunction.KEEP_BOUNDARY_STATES
+                and any(ctx.needs_input_grad[:3]))
         out = bk_forward(a2.detach(), b2.detach(), c2.detach(), z, raw=False,
                          phi_exact=(BKCoreFunction.PHI_K_INDEX == "exact"),
                          share_storage=BKCoreFunction.SHARE_FEATURES_STORAGE, want_states=keep)

@@ -598,10 +598,19 @@ struct Raw {
 template <bool CHECK>
 __device__ __forceinline__ void issue_loads(const float *__restrict__ a, const float *__restrict__ b,
                                             const float *__restrict__ c, const float *__restrict__ G,
-                                            const float *__restrict__ gf, const float4 *__restrict__ bst, long base,
+                                            const float *__restrict__ gf, const float2 *__restrict__ bst, long base,
                                             long N, Raw &R, int t) {
+  // boundary states: per row the forward keeps two planes of one float2 per block of 8 elements -- plane 0: om(r)
+  // entering block m, plane 1: om(s) at the block's second element, i.e. two elements past block m - 1; the planes cover
+  // whole chunks of 4096 elements plus one block
   R.st = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (bst && base + (long)t * EB < N) R.st = bst[base / EB + t];
+  if (bst && base + (long)t * EB < N) {
+    const long m = base / EB + t;
+    const long plane = ((N + 4095) / 4096) * 512 + 1;
+    const float2 th = bst[m];
+    const float2 ph = bst[plane + m + 1];
+    R.st = make_float4(th.x, th.y, ph.x, ph.y);
+  }
   const float *__restrict__ pa = a + (base - WH);       // slot q: a[base - WH + q]
   const float *__restrict__ pb = b + (base - WH - 1);   // slot q holds k_{i-1}, i = base - WH + q
   const float *__restrict__ pc = c + (base - WH - 1);
@@ -644,7 +653,7 @@ __device__ __forceinline__ void issue_loads(const float *__restrict__ a, const f
 }
 __device__ __forceinline__ void issue_chunk(const float *__restrict__ a, const float *__restrict__ b,
                                             const float *__restrict__ c, const float *__restrict__ G,
-                                            const float *__restrict__ gf, const float4 *__restrict__ bst, long base,
+                                            const float *__restrict__ gf, const float2 *__restrict__ bst, long base,
                                             long N, Raw &R, int t) {
   if (base - WH - 1 >= 0 && base + CHUNK + WH - 1 <= N - 1) issue_loads<false>(a, b, c, G, gf, bst, base, N, R, t);
   else issue_loads<true>(a, b, c, G, gf, bst, base, N, R, t);
@@ -728,7 +737,7 @@ __global__ __launch_bounds__(T, BK_SWEEP_WG) void bk_adjoint_sweeps(
   float *gb = gb_ ? gb_ + row * (N - 1) : nullptr;
   float *gc = gc_ ? gc_ + row * (N - 1) : nullptr;
   const float2 z = z_dev ? make_float2(z_dev[0], z_dev[1]) : make_float2(z_re, z_im);
-  const float4 *bst = SAVED ? bst_ + row * ((N + EB - 1) / EB) : nullptr;
+  const float2 *bst = SAVED ? reinterpret_cast<const float2 *>(bst_) + row * (2 * (((N + 4095) / 4096) * 512 + 1)) : nullptr;
   const int t = threadIdx.x;
   const int nch = N <= CHUNK ? 1 : 1 + (int)((N - CHUNK + STRIDE - 1) / STRIDE);  // (index of the debug stamps)
   (void)nch;
@@ -1176,17 +1185,20 @@ int bkcore_backward_analytic(const float *a, int64_t lda, const float *b, int64_
                              const float *grad_features, const float *grad_G, float *grad_a, float *grad_b,
                              float *grad_c, void *workspace, size_t workspace_bytes, void *state, unsigned flags,
                              void *stream) {
-  return bkcore_backward_analytic_states(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G_saved, nullptr,
+  return bkcore_backward_analytic_states(a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G_saved, nullptr, 0,
                                          grad_features, grad_G, grad_a, grad_b, grad_c, workspace, workspace_bytes,
                                          state, flags, stream);
 }
 
 int bkcore_backward_analytic_states(const float *a, int64_t lda, const float *b, int64_t ldb, const float *c,
                                     int64_t ldc, const float *z_dev, float z_re, float z_im, int64_t B, int64_t N,
-                                    const float *G_saved, const float *boundary_states, const float *grad_features,
-                                    const float *grad_G, float *grad_a, float *grad_b, float *grad_c, void *workspace,
-                                    size_t workspace_bytes, void *state, unsigned flags, void *stream) {
+                                    const float *G_saved, const float *boundary_states, size_t boundary_state_bytes,
+                                    const float *grad_features, const float *grad_G, float *grad_a, float *grad_b,
+                                    float *grad_c, void *workspace, size_t workspace_bytes, void *state, unsigned flags,
+                                    void *stream) {
   if (boundary_states && !G_saved) return BKCORE_EINVAL;  // the states belong to the forward call that produced G
+  if (boundary_states && B > 0 && N > 0 && boundary_state_bytes < bkcore_boundary_state_bytes(B, N))
+    return BKCORE_EWORKSPACE;
   if (B < 0 || N < 0 || lda < 0 || ldb < 0 || ldc < 0) return BKCORE_EINVAL;
   if (B == 0 || N == 0) return BKCORE_OK;
   if (!a || !grad_a || (N > 1 && (!b || !c))) return BKCORE_EINVAL;

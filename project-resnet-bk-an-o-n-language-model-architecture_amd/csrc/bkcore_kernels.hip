@@ -1421,7 +1421,7 @@ inline int ratio_form_plan(int64_t B, int64_t N, int in_dtype, bool phi_exact, u
   if (flags & BKCORE_FLAG_ADAPTIVE)  // (its shortcut lives in the whole-row kernel)
     return (chunks_possible && B <= 128 && nch >= 8) ? FORM_CHUNKS : FORM_WHOLE;
   int per_cu = 0;  // of the unit kernel; 0: units not available
-  if (!long_rows && !keeps_states && !(flags & BKCORE_FLAG_WHOLE_ROWS)) {
+  if (!long_rows && !(flags & BKCORE_FLAG_WHOLE_ROWS)) {
     if (cus_given > 0) per_cu = sixteen ? 2 : 3;
     else per_cu = bkcore_internal_ratio_unit_occupancy(in_dtype, phi_exact);
   }
@@ -1514,7 +1514,7 @@ int launch_forward2(const void *a, int64_t lda, const void *b, int64_t ldb, cons
     if (form != FORM_UNITS || per_cu <= 0) RS = 1;
     if (RS > 1)
       fwd(dtype_tag<TIn>(), PHI_EXACT, 3, per_cu * device_cu_count(), a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
-          flags, fclamp, RS, rseg, nullptr, nullptr, stream);
+          flags, fclamp, RS, rseg, bstates, nullptr, stream);
     else if (bstates && !SAVE)
       fwd(dtype_tag<TIn>(), PHI_EXACT, 0, 2, a, lda, b, ldb, c, ldc, z_dev, z_re, z_im, B, N, G, features, ws, state,
           flags, fclamp, 1, 0, bstates, nullptr, stream);
@@ -1631,13 +1631,15 @@ int bkcore_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const
 
 size_t bkcore_boundary_state_bytes(int64_t B, int64_t N) {
   if (B <= 0 || N <= 0) return 0;
-  return (size_t)B * (size_t)((N + 7) / 8) * 4 * sizeof(float);
+  // per row two planes of one float2 per block of 8 elements of whole chunks of 4096, plus one block
+  return (size_t)B * 2 * (size_t)(((N + 4095) / 4096) * 512 + 1) * 2 * sizeof(float);
 }
 
 int bkcore_forward_states(const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc, int in_dtype,
                           const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, float *features,
-                          float feature_clamp, float *boundary_states, int *states_written, void *workspace,
-                          size_t workspace_bytes, void *state, unsigned flags, void *stream) {
+                          float feature_clamp, float *boundary_states, size_t boundary_state_bytes,
+                          int *states_written, void *workspace, size_t workspace_bytes, void *state, unsigned flags,
+                          void *stream) {
   if (states_written) *states_written = 0;
   if (!boundary_states)
     return bkcore_forward_clamped(a, lda, b, ldb, c, ldc, in_dtype, z_dev, z_re, z_im, B, N, G, features, feature_clamp,
@@ -1651,6 +1653,7 @@ int bkcore_forward_states(const void *a, int64_t lda, const void *b, int64_t ldb
   if (B > 2147483647LL) return BKCORE_EINVAL;
   const size_t need = bkcore_workspace_bytes(B, N);
   if (need > 0 && (!workspace || workspace_bytes < need)) return BKCORE_EWORKSPACE;
+  if (boundary_state_bytes < bkcore_boundary_state_bytes(B, N)) return BKCORE_EWORKSPACE;
   if (!forward_writes_states(in_dtype, N, state, flags))
     return bkcore_forward_clamped(a, lda, b, ldb, c, ldc, in_dtype, z_dev, z_re, z_im, B, N, G, features, feature_clamp,
                                   workspace, workspace_bytes, state, flags, stream);
@@ -1884,7 +1887,7 @@ int bkcore_forward_plan(int64_t B, int64_t N, int in_dtype, unsigned flags, int 
 }
 int bkcore_last_hip_error(void) { return g_last_hip_error; }
 void bkcore_internal_set_hip_error(int code) { g_last_hip_error = code; }
-int bkcore_abi_version(void) { return 16; }
+int bkcore_abi_version(void) { return 17; }
 
 const char *bkcore_error_string(int code) {
   switch (code) {

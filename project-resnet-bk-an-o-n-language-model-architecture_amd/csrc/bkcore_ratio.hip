@@ -498,15 +498,18 @@ __device__ __forceinline__ unsigned commit_ratio(const RowCfg &cfg, const float 
 // MODE 0, bit for bit.
 // SAVE (MODE 0 only, for the analytic backward): also stores r_j and s_j, and writes G_raw (before the final
 // log-magnitude clamp and the clip; 0 outside 1e-18 <= |G_raw| <= 1e18) instead of G.
-// BST (float32 chains, MODE 0 / 4, for the analytic backward): also stores, for every block of BST_BLOCK = 8
-// elements m, the two values the ratio chains of that block start from -- om(r_{8m-1}), what the theta chain carries
-// into the block from the left, and om(s_{8m+9}), what the phi chain carries towards it from the right (one more step,
-// at element 8m+8, gives the backward the terms it needs of that element) -- as one record of two complex numbers in
-// save_r_ (16 bytes per 8 elements; record 0's first half is never written: the theta chain enters a row with 0).
-constexpr int BST_BLOCK = 8;
-static_assert(E == 2 * BST_BLOCK, "a lane's elements are two blocks of the analytic backward");
+// BST (float32 chains, for the analytic backward): also stores, for every block of 8 elements m, the two values the ratio
+// chains of that block start from -- om(r_{8m-1}), what the theta chain carries into the block from the left, and
+// om(s_{8m+9}), what the phi chain carries towards it from the right (one more step, at element 8m+8, gives the backward
+// the terms it needs of that element) -- in save_r_, per row two planes of one complex number per block: plane 0 holds
+// om(r_{8m-1}) at index m, plane 1 om(s_{8m+1}) at index m (a wave's store is then one strided run of 8-byte pieces).
+// Each value is stored the moment it exists, at an address worked out on the spot, and the planes are padded to whole
+// chunks plus one block so that no store needs a bounds test: anything that lives across the chains, or any condition
+// around the stores, costs this kernel its budget of three workgroups per CU (a variant that kept the four values
+// until the end of the chunk spilled 100-156 registers there).
+static_assert(E == 16, "one record per lane and chunk");
 template <typename TIn, bool PHI_EXACT, int MODE, bool SAVE = false, bool BST = false>
-__global__ __launch_bounds__(RT, BST ? 2 : (MODE == 4 && (!LONG || BK_LOOK_LONG3)) ? BK_RATIO_WAVES : ((MODE == 0 || MODE == 3) && !SAVE && !LONG && sizeof(TIn) != 2) ? BK_RATIO_WAVES : 2) void bk_ratio_forward_kernel(
+__global__ __launch_bounds__(RT, (MODE == 4 && (!LONG || BK_LOOK_LONG3)) ? BK_RATIO_WAVES : ((MODE == 0 || MODE == 3) && !SAVE && !LONG && sizeof(TIn) != 2) ? BK_RATIO_WAVES : 2) void bk_ratio_forward_kernel(
     const TIn *__restrict__ a_, long lda, const TIn *__restrict__ b_, long ldb, const TIn *__restrict__ c_, long ldc,
     const float *__restrict__ z_dev, float z_re, float z_im, long B, long N_, float2 *__restrict__ G_,
     float2 *__restrict__ F_, char *__restrict__ ws, int *state, unsigned flags, float fclamp, int S,
@@ -566,9 +569,11 @@ __global__ __launch_bounds__(RT, BST ? 2 : (MODE == 4 && (!LONG || BK_LOOK_LONG3
   float2 *G = G_ + row * N_ + shift;
   float2 *F = F_ ? F_ + row * N_ + shift : nullptr;
   // boundary states of the row (two complex numbers per block), in the unit's coordinates like everything else
-  float4 *bst = BST ? reinterpret_cast<float4 *>(save_r_) + row * ((N_ + BST_BLOCK - 1) / BST_BLOCK) + shift / BST_BLOCK
-                    : nullptr;
-  const long nblk = (N + BST_BLOCK - 1) / BST_BLOCK;  // blocks from the unit's first element to the end of the row
+  // boundary states of the row: two planes of one float2 per block of 8 elements (the blocks of whole chunks, plus
+  // one) -- om(r) entering the block, then om(s) at the block's second element --, in the unit's coordinates like
+  // everything else
+  const long bst_plane = ((N_ + RCHUNK - 1) / RCHUNK) * (2 * RT) + 1;
+  float2 *bst16 = BST ? reinterpret_cast<float2 *>(save_r_) + row * (2 * bst_plane) + shift / 8 : nullptr;
   const int nch = (int)((N + RCHUNK - 1) / RCHUNK);
   const int ch0 = LOOK ? nch - 1 - sg : 0;
   const int ch1 = LOOK ? ch0 + 1 : RELAY ? min(nch, seg_ch) : nch;  // (a unit: seg_ch chunks from its start)
@@ -602,9 +607,7 @@ __global__ __launch_bounds__(RT, BST ? 2 : (MODE == 4 && (!LONG || BK_LOOK_LONG3
   // (2 waves per SIMD).
   // 16-bit operands (the layer's bfloat16 diagonal) measured faster with two workgroups per CU and the prefetch:
   // twice the load instructions per byte
-  // (the variant that keeps the boundary states does not fit three workgroups per CU: anything more that lives across
-  // the chunk loop makes the compiler spill a hundred registers at that budget; it runs two per CU with the prefetch)
-  constexpr bool PREFETCH = !((MODE == 0 || MODE == 3) && !SAVE && !BST && BK_RATIO_WAVES >= 3 && sizeof(TIn) != 2) && !LONG && !LOOK && BK_RATIO_PREFETCH;
+  constexpr bool PREFETCH = !((MODE == 0 || MODE == 3) && !SAVE && BK_RATIO_WAVES >= 3 && sizeof(TIn) != 2) && !LONG && !LOOK && BK_RATIO_PREFETCH;
   float av[RNJ], bv[RNJ], cv[RNJ];
   auto prefetch = [&](int ch) __attribute__((always_inline)) {
     // `full`: the chunk and its halos (and the one extra k) lie inside the row
@@ -743,18 +746,29 @@ __global__ __launch_bounds__(RT, BST ? 2 : (MODE == 4 && (!LONG || BK_LOOK_LONG3
     const float2 th_west = to_f2(wt), ph_west = to_f2(wp);
 
     BK_STAMP(4);
-    float2 bs_tmid = make_float2(0.f, 0.f), bs_p9 = bs_tmid, bs_p1 = bs_tmid;  // (BST) boundary states of the lane
     // theta over the lane's own elements, left -> right: keeps 1 / r_e
 #pragma unroll
     for (int j = 0; j < E; ++j) {
       wt = ratio_step(al_l[roff(j)], k_l[roff(j)], wt, r, inv, lmin);
       ir[j] = inv;
       if constexpr (BST) {
-        if (j == BST_BLOCK - 1) bs_tmid = to_f2(wt);  // what enters the lane's second block
+        if (j == 7) {  // om(r) behind the lane's eighth element: what enters its second block of 8
+          int tv = threadIdx.x;
+          asm volatile("" : "+v"(tv));
+          float *dst = reinterpret_cast<float *>(bst16 + (base >> 3) + 2 * (RT - 1 - tv) + 1);
+          const float2 tm = to_f2(wt);
+          *reinterpret_cast<float2 *>(dst) = tm;  // (plain stores: the other half of the line follows within the chunk)
+        }
       }
       BK_SCHED_FENCE(j);
     }
     const float2 th_fin = to_f2(wt);
+    if constexpr (BST) {  // om(r) behind the lane's last element: what enters the next block of 16
+      int tv = threadIdx.x;
+      asm volatile("" : "+v"(tv));
+      float *dst = reinterpret_cast<float *>(bst16 + (base >> 3) + 2 * (RT - 1 - tv) + 2);
+      *reinterpret_cast<float2 *>(dst) = th_fin;
+    }
 
     BK_STAMP(5);
     // phi right -> left with the lane-local products folded in: loc_e = (1/r_e) * prod_{e' > e} s_e' / r_e' replaces
@@ -767,9 +781,14 @@ __global__ __launch_bounds__(RT, BST ? 2 : (MODE == 4 && (!LONG || BK_LOOK_LONG3
       const int e = E - 1 - j;
       wp = ratio_step_om(al_l[roff(e)], k_l[roff(e + KO)], wp, r, lmin);
       if (TAIL && i0 + e >= N) wp = c2((Real)0, (Real)0);
-      if constexpr (BST) {  // om(s) at the second element after the end of a block
-        if (e == BST_BLOCK + 1) bs_p9 = to_f2(wp);
-        if (e == 1) bs_p1 = to_f2(wp);
+      if constexpr (BST) {  // om(s) at the lane's second element: one step short of what enters the block to the left
+        if (e == 1 || e == 9) {  // (e == 9: the same for the lane's second block of 8)
+          int tv = threadIdx.x;
+          asm volatile("" : "+v"(tv));
+          float *dst = reinterpret_cast<float *>(bst16 + bst_plane + (base >> 3) + 2 * (RT - 1 - tv) + (e == 9 ? 1 : 0));
+          const float2 p1 = to_f2(wp);
+          *reinterpret_cast<float2 *>(dst) = p1;
+        }
       }
       const bool valid = !TAIL || i0 + e < N;
       const C2 loc = cmulr(ir[e], run.m);
@@ -788,30 +807,6 @@ __global__ __launch_bounds__(RT, BST ? 2 : (MODE == 4 && (!LONG || BK_LOOK_LONG3
     }
 #endif
     const float2 ph_fin = to_f2(wp);
-    if constexpr (BST) {
-      // the lane's elements are blocks m0 and m0 + 1: theta states enter blocks m0 + 1 and m0 + 2, phi states belong to
-      // blocks m0 - 1 (om(s) at the lane's element 1) and m0 (element 9); -1 is the last block of the unit to the left
-      const int m0 = (int)(i0 / BST_BLOCK);
-      const int nb = (int)nblk;
-      float *dst = reinterpret_cast<float *>(bst) + 4 * m0;
-      if (m0 + 1 < nb) {
-        __builtin_nontemporal_store(bs_tmid.x, dst + 4);
-        __builtin_nontemporal_store(bs_tmid.y, dst + 5);
-      }
-      if (m0 + 2 < nb) {
-        __builtin_nontemporal_store(th_fin.x, dst + 8);
-        __builtin_nontemporal_store(th_fin.y, dst + 9);
-      }
-      if (m0 < nb) {
-        __builtin_nontemporal_store(bs_p9.x, dst + 2);
-        __builtin_nontemporal_store(bs_p9.y, dst + 3);
-      }
-      if ((m0 >= 1 || left_open) && m0 - 1 < nb) {
-        __builtin_nontemporal_store(bs_p1.x, dst - 2);
-        __builtin_nontemporal_store(bs_p1.y, dst - 1);
-      }
-    }
-
     BK_STAMP(6);
     bad |= !(lmin >= WALL_LN_MIN);  // a ratio below 1e-2 in magnitude: outside the clamp factor's series
     if constexpr (SAVE) {
@@ -1208,8 +1203,9 @@ void ratio_launch(int mode, int save, const void *a, long lda, const void *b, lo
   // (float32 operands, float32 chains)
 #if !BK_RATIO_LONG
   if constexpr (std::is_same<TIn, float>::value) {
-    if (save_r != nullptr && (mode == 4 || (mode == 0 && save == 2))) {
+    if (save_r != nullptr && (mode == 4 || mode == 3 || (mode == 0 && save == 2))) {
       if (mode == 4) BK_RATIO2(4, false, true, B * S);
+      else if (mode == 3) BK_RATIO2(3, false, true, (BK_RELAY_PERSIST && save > 0 && save < B * S) ? save : B * S);
       else BK_RATIO2(0, false, true, B);
       return;
     }

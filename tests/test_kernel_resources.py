@@ -87,14 +87,16 @@ def test_forward_in_chunks_keeps_the_same_budget(kernels):
         assert per_cu * r["group_segment_fixed_size"] <= 160 * 1024, (k, r)
 
 
-def test_forward_keeping_boundary_states_runs_two_per_cu(kernels):
-    # BST true: does not fit the three-per-CU budget (a hundred spilled registers there); two per CU, no real spilling
+def test_forward_keeping_boundary_states_keeps_the_same_budget(kernels):
+    # bk_ratio_forward_kernel<float, PHI_EXACT, MODE 0 / 3 / 4, SAVE false, BST true>: the variant that also stores the
+    # values its chains carry into every block of 8 elements (each stored the moment it exists, at an address worked
+    # out on the spot) runs three workgroups per CU like the plain one
     hits = _find(kernels, "bk_ratio_forward_kernelIfLb", "ELb0ELb1E")
-    assert len(hits) == 4, hits                                       # MODE 0 and 4, both phi conventions
+    assert len(hits) == 6, hits                                       # MODE 0, 3 and 4, both phi conventions
     for k in hits:
         r = kernels[k]
-        assert r["vgpr_count"] <= 256 and r["private_segment_fixed_size"] <= 32, (k, r)
-        assert 2 * r["group_segment_fixed_size"] <= 160 * 1024, (k, r)
+        assert r["vgpr_count"] <= 168 and r["private_segment_fixed_size"] <= 16, (k, r)
+        assert 3 * r["group_segment_fixed_size"] <= 160 * 1024, (k, r)
 
 
 def test_one_pass_analytic_backward_does_not_spill(kernels):
