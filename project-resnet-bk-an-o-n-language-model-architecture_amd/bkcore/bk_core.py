@@ -173,7 +173,8 @@ def bk_forward(a, b, c, z, raw: bool = False, phi_exact: bool = False, want_feat
     share_storage: without a clamp the features are bit for bit the (re, im) pairs of G (bk_core.py:296-298), so they
     are returned as the float32 view of G instead of a second 8-byte-per-element write.
     want_states: returns (features|None, G, states|None) -- the boundary states of the ratio chains for
-    bk_backward_analytic (a (B, ceil(N/8), 4) float32 tensor, or None when this call's path does not keep them)."""
+    bk_backward_analytic (a float32 tensor of bkcore_boundary_state_bytes(B, N) bytes, or None when this call's path does
+    not keep them)."""
     L = _lib.load()
     a, b, c, dt = _prep_inputs(a, b, c)
     B, N = a.shape
@@ -210,7 +211,7 @@ def bk_forward(a, b, c, z, raw: bool = False, phi_exact: bool = False, want_feat
             if not fc > 0.0:
                 raise ValueError("bkcore: feature_clamp must be positive")
         if want_states and dt == _lib.F32:
-            st_bytes = int(L.bkcore_boundary_state_bytes(B, N))   # one float4 per block of 16, rows padded
+            st_bytes = int(L.bkcore_boundary_state_bytes(B, N))   # 16 bytes per block of 8, rows padded
             states = torch.empty((B, st_bytes // (16 * B), 4), dtype=torch.float32, device=dev)
             written = ctypes.c_int(0)
             rc = L.bkcore_forward_states(pa, lda, pb if nb else None, ldb, pc if nb else None, ldc, dt, pz, zre, zim,
