@@ -130,3 +130,92 @@ def test_buffers_stay_inside_their_bounds(B, N, dtype, flag_names, keep):
                           ("state block", state), ("G", G), ("boundary states", states)):
             assert buf.intact(), f"{name}: guard region overwritten by the analytic backward"
         assert bool(torch.isfinite(ga.f32()).all())
+
+
+@pytest.mark.parametrize("outer,Lseq,inner,reverse", [(1, 1, 1, 0), (3, 1000, 1, 1), (7, 4097, 1, 0), (2, 70001, 1, 1),
+                                                         (5, 333, 32, 0), (8, 2048, 32, 1), (3, 8191, 7, 0),
+                                                         (130, 1025, 33, 1), (1, 50000, 3, 0)])
+def test_cumsum_stays_inside_its_output(outer, Lseq, inner, reverse):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bkcore import _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(outer * 7 + Lseq)
+    x = torch.randint(-3, 4, (outer, Lseq, inner), generator=g).float()
+    xd = x.cuda().contiguous()
+    y = Guarded(x.numel() * 4)
+    rc = L.bkcore_cumsum(xd.data_ptr(), y.ptr(), outer, Lseq, inner, reverse, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert y.intact()
+    ref = x.double().flip(1).cumsum(1).flip(1) if reverse else x.double().cumsum(1)
+    assert torch.equal(y.f32().view(outer, Lseq, inner).cpu().double(), ref)     # integer-valued input: exact
+
+
+@pytest.mark.parametrize("B,N,r", [(1, 5, 1), (3, 1000, 4), (16, 4097, 15), (64, 2049, 16), (9, 70001, 22), (130, 300, 7)])
+def test_woodbury_stays_inside_its_buffers(B, N, r):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bkcore import _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(B + N + r)
+    Gc = (torch.randn(B, N, 2, generator=g) * 0.3).cuda().contiguous()
+    U = (torch.randn(N, r, generator=g) * 0.1).cuda().contiguous()
+    V = (torch.randn(N, r, generator=g) * 0.1).cuda().contiguous()
+    out = Guarded(B * N * 8)
+    ws = Guarded(L.bkcore_woodbury_workspace_bytes(B, N, r))
+    rc = L.bkcore_woodbury_correct(Gc.data_ptr(), U.data_ptr(), V.data_ptr(), B, N, r, out.ptr(), ws.ptr(), ws.n,
+                                   torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    assert out.intact() and ws.intact()
+    # float64 restatement of the loop over the batch (birman_schwinger_core.py:567-604)
+    Gz = (Gc[..., 0].double() + 1j * Gc[..., 1].double()).cpu()
+    Uc, Vc = U.double().cpu().to(torch.complex128), V.double().cpu().to(torch.complex128)
+    ref = torch.empty_like(Gz)
+    for i in range(B):
+        M = torch.eye(r, dtype=torch.complex128) + Vc.T @ (Gz[i][:, None] * Uc)
+        W = torch.linalg.inv(M)
+        ref[i] = Gz[i] - Gz[i] ** 2 * ((Uc @ W) * Vc).sum(-1)
+    got = out.f32().view(B, N, 2).cpu().double()
+    got = got[..., 0] + 1j * got[..., 1]
+    assert float((got - ref).abs().max() / ref.abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("B,N,D", [(1, 1, 256), (3, 257, 256), (2, 1000, 512), (5, 77, 96), (8, 256, 1024)])
+def test_layer_steps_stay_inside_their_buffers(B, N, D):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bkcore import _lib
+    L = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(B * 31 + N)
+    n = B * N
+    v = torch.randn(B, N, generator=g).cuda()
+    h0 = torch.full((N,), -2.0).cuda()
+    he = Guarded(n * 2)
+    assert L.bkcore_layer_prologue(v.data_ptr(), N, h0.data_ptr(), 3.0, B, N, he.ptr(), _lib.BF16, stream) == 0
+    feats = (torch.randn(n, 2, generator=g) * 0.5).cuda()
+    gfe = torch.randn(n, 2, generator=g).cuda()
+    gv = Guarded(n * 4)
+    assert L.bkcore_layer_backward_ref(feats.data_ptr(), gfe.data_ptr(), None, 0.5, 10.0, v.data_ptr(), 3.0, 1, n,
+                                       gv.ptr(), stream) == 0
+    w = torch.randn(D, 2, generator=g).cuda()
+    bias = torch.randn(D, generator=g).cuda()
+    scale = torch.randn(D, generator=g).cuda()
+    res = torch.randn(n, D, generator=g).cuda()
+    out = Guarded(n * D * 4)
+    assert L.bkcore_layer_epilogue_clamped(feats.data_ptr(), 10.0, w.data_ptr(), bias.data_ptr(), scale.data_ptr(),
+                                           res.data_ptr(), n, D, out.ptr(), stream) == 0
+    go = torch.randn(n, D, generator=g).cuda()
+    gfeat, gw, gb, gs = Guarded(n * 8), Guarded(D * 8), Guarded(D * 4), Guarded(D * 4)
+    wsb = Guarded(L.bkcore_layer_epilogue_backward_workspace_bytes(n, D))
+    assert L.bkcore_layer_epilogue_backward_clamped(go.data_ptr(), feats.data_ptr(), 10.0, w.data_ptr(), bias.data_ptr(),
+                                                    scale.data_ptr(), n, D, gfeat.ptr(), gw.ptr(), gb.ptr(), gs.ptr(),
+                                                    wsb.ptr(), wsb.n, stream) == 0
+    torch.cuda.synchronize()
+    for name, buf in (("he_diag", he), ("grad_v", gv), ("out", out), ("grad_features", gfeat), ("grad_weight", gw),
+                      ("grad_bias", gb), ("grad_scale", gs), ("workspace", wsb)):
+        assert buf.intact(), name
+    ref = res + scale * (feats.clamp(-10, 10) @ w.T + bias)
+    assert float((out.f32().view(n, D) - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
