@@ -271,3 +271,33 @@ def test_units_repeatable_under_other_work(bk):
     torch.cuda.synchronize()
     st = bk_core._state_block(a.device, torch.cuda.current_stream().cuda_stream).tolist()
     assert bad == 0 and st[12] == 0 and st[2] == 0
+
+
+def test_units_on_two_streams_at_once(bk):
+    """Two forwards of the headline shape on two streams at once, each in the form whose grid assumes the GPU to itself
+    (each stream has its own state block and workspace): the bits of the serial results, and no hand-over given up (a
+    given-up hand-over costs 50 ms)."""
+    import time
+    from bkcore import bk_core
+    bk_core._DEBUG["keep_ws"] = False
+    B, N = 1024, 8 * CH
+    xs = [_inputs(B, N, seed=31), _inputs(B, N, seed=32)]
+    z = torch.tensor(1j, dtype=torch.complex64, device="cuda")
+    ref = [bk.bk_forward(*x, z)[1].clone() for x in xs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for s, x in zip(streams, xs):
+        with torch.cuda.stream(s):
+            bk.bk_forward(*x, z)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for _ in range(40):
+        outs = []
+        t0 = time.perf_counter()
+        for s, x in zip(streams, xs):
+            with torch.cuda.stream(s):
+                outs.append(bk.bk_forward(*x, z)[1])
+        torch.cuda.synchronize()
+        worst = max(worst, time.perf_counter() - t0)
+        for o, r in zip(outs, ref):
+            assert torch.equal(torch.view_as_real(o), torch.view_as_real(r))
+    assert worst < 0.03, worst
