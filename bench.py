@@ -144,7 +144,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     on_gpu = args.device == "cuda"
     dist = None
-    if world > 1:
+    # (BENCH_FORCE_DIST=1 under torch.distributed.run with ONE rank takes the collective path all the same: the
+    # rendezvous, barrier, all-gather and MAX-reduction over RCCL can then be rehearsed on a one-GPU box)
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         if on_gpu:
             torch.cuda.set_device(local_rank)
@@ -190,7 +193,7 @@ def main():
             pass
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         sync()
 
@@ -272,7 +275,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     rank_ms = [dt / args.steps * 1e3]
-    if world > 1:
+    if use_dist:
         # every rank's own time (a later scaling run shows skew between ranks), then the MAX that is reported
         mine = torch.tensor([dt], dtype=torch.float64, device=device)
         every = [torch.zeros_like(mine) for _ in range(world)]
@@ -296,8 +299,8 @@ def main():
             "ms_per_step": ms,
             "ms_per_step_ranks": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
             "world": {"env_world_size": world,
-                      "torch_distributed_world_size": dist.get_world_size() if world > 1 else 1,
-                      "backend": (dist.get_backend() if world > 1 else None)},
+                      "torch_distributed_world_size": dist.get_world_size() if use_dist else 1,
+                      "backend": (dist.get_backend() if use_dist else None)},
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
@@ -342,7 +345,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(N)
                 out["cpu_baseline_reference_cost_model"] = cpu_baseline_torch_loop()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
