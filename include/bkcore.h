@@ -187,7 +187,7 @@ size_t bkcore_backward_analytic_workspace_bytes(int64_t B, int64_t N);
  * elements, rows padded to whole chunks of 4096 plus one block -- bkcore_boundary_state_bytes(B, N) in all -- into
  * boundary_states (device memory, 16-byte aligned, boundary_state_bytes long: BKCORE_EWORKSPACE if that is less than
  * bkcore_boundary_state_bytes(B, N)).  *states_written (host int, may be NULL) says whether this call's
- * path wrote them: yes for float32 operands with a state block, rows of at most 131072 elements and none of
+ * path wrote them: yes for float32 operands with a state block, rows of at most 49152 elements and none of
  * BKCORE_FLAG_SCAN_PATH / BKCORE_FLAG_ADAPTIVE; otherwise the call is bkcore_forward_clamped and the backward has to
  * be given NULL.  boundary_states == NULL: plain bkcore_forward_clamped.
  *

@@ -32,8 +32,11 @@ extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_ratio_forw
     float *features, void *ws, void *state, unsigned flags, float fclamp, int S, int seg_ch, float *save_r,
     float *save_s, void *stream);
 // The same launch with double-precision chains and product (bkcore_ratio_long.hip; no saving variant), taken for
-// rows longer than BKCORE_INTERNAL_LONG_ROW elements.
-#define BKCORE_INTERNAL_LONG_ROW 131072
+// rows longer than BKCORE_INTERNAL_LONG_ROW elements.  With float32 chains the rounding of the N factors of the running
+// product is a random walk; the worst row of 54 per setting measured (tools/dev_err_vs_n.py, against the C oracle, for
+// z = 1j, 0.8j, 0.7j, -0.4+0.8j, 0.45+0.75j): N = 32768 4.1e-5, 49152 5.0e-5, 65536 6.7e-5, 98304 7.6e-5, 131072 1.03e-4.
+// The operator's bound is 1e-4, so float32 stops at 49152 (twelve chunks).
+#define BKCORE_INTERNAL_LONG_ROW 49152
 extern "C" __attribute__((visibility("hidden"))) void bkcore_internal_ratio_forward_long(
     int in_dtype, int phi_exact, int mode, int save, const void *a, int64_t lda, const void *b, int64_t ldb,
     const void *c, int64_t ldc, const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G,

@@ -119,7 +119,7 @@ def test_forward_plan_policy():
     assert plan(1024, 32768, _lib.BF16) == (8, 2)   # 16-bit operands: chunks wherever units would be considered
     assert plan(600, 32768, _lib.BF16) == (8, 2)
     assert plan(1024, 32768, flags=_lib.FLAG_ADAPTIVE) == (1, 2)
-    assert plan(1024, 1 << 18) == (1, 2)            # rows beyond 131072 elements run in double, two workgroups per CU
+    assert plan(1024, 1 << 18) == (1, 2)            # rows beyond 49152 elements run in double, two workgroups per CU
     assert plan(600, 1 << 18) == (64, 2)
     assert plan(16, 1 << 20) == (256, 2)            # few long rows: one workgroup per chunk, handing over in the launch
     s, l = plan(16, 1 << 20, flags=_lib.FLAG_SCAN_PATH)

@@ -299,7 +299,7 @@ def test_argument_checks(bk):
 
 @pytest.mark.parametrize("B,N,exact", [(3, 8, False), (2, 9, False), (2, 17, True), (3, 2031, False), (2, 2033, False),
                                        (3, 4095, True), (2, 4097, False), (4, 6112, False), (130, 8197, False),
-                                       (5, 40000, False), (16, 65545, True), (2, 32768, False)])
+                                       (5, 40000, False), (16, 49145, True), (2, 32768, False)])
 def test_backward_from_kept_boundary_states(bk, B, N, exact):
     """The forward that also keeps what its ratio chains carry into every block of 8 elements
     (bkcore_forward_states) and the backward that starts from it (bkcore_backward_analytic_states): same gradients as
@@ -354,7 +354,7 @@ def test_boundary_states_of_a_recomputed_row_are_not_trusted(bk):
 
 def test_autograd_keeping_boundary_states(bk):
     """BKCoreFunction in analytic mode with KEEP_BOUNDARY_STATES: the same gradients as without (to rounding); rows
-    longer than 131072 elements and 16-bit operands fall back to the recomputing backward by themselves."""
+    longer than 49152 elements and 16-bit operands fall back to the recomputing backward by themselves."""
     bk.BKCoreFunction.GRAD_MODE = "analytic"
     try:
         for B, N, dt in ((3, 5000, torch.float32), (2, 140000, torch.float32), (2, 3000, torch.bfloat16)):

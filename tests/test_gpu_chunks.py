@@ -67,14 +67,15 @@ def test_plan_is_two_launches(bk):
 
 
 @pytest.mark.parametrize("B,N,dtype,conv", [
-    (2, 63 * CH + 11, torch.float32, "reference"),     # double chains (N > 131072), no anchor yet
+    (2, 63 * CH + 11, torch.float32, "reference"),     # double chains (N > 49152), no anchor yet
     (2, 64 * CH, torch.float32, "reference"),          # the first anchor is the row's last chunk: nothing reads it
     (3, 64 * CH + 1, torch.float32, "exact"),          # one chunk reads the anchor alone
     (2, 65 * CH + 4000, torch.bfloat16, "reference"),
     (1, 128 * CH + 17, torch.float64, "reference"),    # two anchors, a ragged last chunk
     (2, 130 * CH - 5, torch.float16, "reference"),
     (128, 8 * CH, torch.float32, "reference"),         # the most rows and the fewest chunks that take this form
-    (7, 32 * CH, torch.float32, "exact"),              # float32 chains at their longest
+    (7, 32 * CH, torch.float32, "exact"),
+    (7, 12 * CH, torch.float32, "exact"),              # float32 chains at their longest
 ])
 def test_parity_across_anchor_boundaries(bk, B, N, dtype, conv):
     from oracle import bk_oracle_c as C

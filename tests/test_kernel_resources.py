@@ -50,7 +50,7 @@ def _find(kernels, *parts):
 
 def test_headline_forward_fits_three_workgroups_per_cu(kernels):
     # bk_ratio_forward_kernel<float, PHI_EXACT, MODE 0, SAVE false, BST false> of the float32 translation unit (the one
-    # for rows longer than 131072, with its chains in double, has the same names and a two-workgroup budget)
+    # for rows longer than 49152, with its chains in double, has the same names and a two-workgroup budget)
     hits = _find(kernels, "bk_ratio_forward_kernelIfLb", "ELi0ELb0ELb0E")
     by_unit = {}
     for k in hits:

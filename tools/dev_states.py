@@ -39,7 +39,7 @@ def case(B, N, seed, varying, exact=False, z=1j):
 import argparse
 ap = argparse.ArgumentParser(); ap.add_argument("--time-only", action="store_true"); args = ap.parse_args()
 for B, N in () if args.time_only else ((3, 8), (2, 9), (2, 17), (3, 2031), (2, 2032), (2, 2033), (3, 2048), (3, 4095), (2, 4097), (4, 6112), (130, 8192 + 5),
-             (5, 40000), (16, 65536 + 9)):
+             (5, 40000), (16, 49152 - 7)):
     case(B, N, N + B, True)
 if not args.time_only:
     case(3, 5000, 1, False)
