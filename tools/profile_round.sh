@@ -14,8 +14,8 @@ timeout -s KILL 90 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_f -o f --output-format
 timeout -s KILL 90 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_w -o w --output-format csv -- python3 $R/tools/prof_fwd.py > $out/pmc_w.log 2>&1
 timeout -s KILL 90 rocprofv3 --pmc FETCH_SIZE -d $out/pa_f -o f --output-format csv -- python3 $R/tools/prof_ana.py 3 > $out/pa_f.log 2>&1 &&
 timeout -s KILL 90 rocprofv3 --pmc WRITE_SIZE -d $out/pa_w -o w --output-format csv -- python3 $R/tools/prof_ana.py 3 > $out/pa_w.log 2>&1 &&
-timeout -k 10 120 rocprofv3 --kernel-trace --stats -d $out/kt_ana -o kt --output-format csv -- python3 $R/tools/prof_ana.py 20 > $out/kt_ana.log 2>&1 &&
-timeout -k 10 120 rocprofv3 --kernel-trace --stats -d $out/kt_ana_st -o kt --output-format csv -- python3 $R/tools/prof_ana.py 20 states > $out/kt_ana_st.log 2>&1
+timeout -k 10 120 rocprofv3 --kernel-trace --stats -d $out/kt_ana -o kt --output-format csv -- python3 $R/tools/prof_ana.py 300 > $out/kt_ana.log 2>&1 &&
+timeout -k 10 120 rocprofv3 --kernel-trace --stats -d $out/kt_ana_st -o kt --output-format csv -- python3 $R/tools/prof_ana.py 300 states > $out/kt_ana_st.log 2>&1
 cd $R
 cp $(find $out/kt -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 cp $(find $out/kt_ana -name "*kernel_stats.csv" | head -1) $out/kernel_stats_analytic.csv
