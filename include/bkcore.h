@@ -113,6 +113,27 @@ int bkcore_forward(const void *a, int64_t lda, const void *b, int64_t ldb, const
 size_t bkcore_workspace_bytes(int64_t B, int64_t N);
 
 /*
+ * The raw resolvent diagonal for complex operands.
+ *
+ * Replaces get_tridiagonal_inverse_diagonal / vmapped_get_diag called with complex he_diag, h0_super, h0_sub:
+ * the reference converts whatever it is given to complex128 (src/models/bk_core.py:45-47) and runs the same
+ * recurrences, regularisation, soft clamps and clip (src/models/bk_core.py:58-210).  BKCoreFunction itself cannot take
+ * complex operands (its input clamp, src/models/bk_core.py:256-258, is not defined for them), so there is no clamped /
+ * sanitised form, no features tensor and no backward here.
+ *
+ * a, b, c: interleaved (re, im) float pairs = complex64; B rows of N (a) and N-1 (b, c) elements, leading dimensions in
+ *    complex elements (0 broadcasts one row).  z, G, stream as for bkcore_forward.
+ * flags: 0 or BKCORE_FLAG_PHI_EXACT; anything else is BKCORE_EINVAL.
+ * workspace: at least bkcore_get_diag_complex_workspace_bytes(B, N) bytes of device scratch.
+ * One launch of the two-scan kernel (no assumption about the input: nothing to verify or recompute); arithmetic in
+ * float32 mantissas with integer exponents like the real-operand kernels, results to 1e-4 of the reference's.
+ */
+int bkcore_get_diag_complex(const float *a, int64_t lda, const float *b, int64_t ldb, const float *c, int64_t ldc,
+                            const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, void *workspace,
+                            size_t workspace_bytes, unsigned flags, void *stream);
+size_t bkcore_get_diag_complex_workspace_bytes(int64_t B, int64_t N);
+
+/*
  * Backward, reference mode: grad_he_diag = (1-alpha) * -Re(conj(g) G^2) + alpha * -Re(conj(g)/G^2) with the
  * reference's stabilisers, where g = grad_features[...,0] + i grad_features[...,1] (+ grad_G).
  * Replaces BKCoreFunction.backward, src/models/bk_core.py:303-385.  alpha is BKCoreFunction.GRAD_BLEND read by

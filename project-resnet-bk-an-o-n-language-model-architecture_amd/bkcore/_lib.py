@@ -20,7 +20,7 @@ FLAG_ROW_UNITS_MUTE = 64
 FLAG_WHOLE_ROWS = 128
 FLAG_ROWS_UNCUT = 256      # diagnostics: one workgroup per row whatever the shape
 STATE_BYTES = 64
-ABI_VERSION = 17
+ABI_VERSION = 18
 EINVAL, ETOOLONG, ELAUNCH, EWORKSPACE, ETOOBIG = -1, -2, -3, -4, -5
 BWD_REFERENCE, BWD_BATCHED, BWD_SCAN_STABLE = 0, 1, 2
 NOALLOC_MAX_WORKSPACE = 8 << 20
@@ -30,6 +30,7 @@ EXPORTS = ("bkcore_forward", "bkcore_forward_clamped", "bkcore_forward_noalloc",
            "bkcore_backward_analytic_workspace_bytes", "bkcore_backward_analytic_rowflag_offset", "bkcore_layer_prologue", "bkcore_layer_backward_ref",
            "bkcore_layer_epilogue", "bkcore_layer_epilogue_backward", "bkcore_layer_epilogue_backward_workspace_bytes",
            "bkcore_layer_epilogue_clamped", "bkcore_layer_epilogue_backward_clamped", "bkcore_cumsum", "bkcore_woodbury_correct", "bkcore_woodbury_workspace_bytes",
+           "bkcore_get_diag_complex", "bkcore_get_diag_complex_workspace_bytes",
            "bkcore_max_seq_len", "bkcore_forward_plan", "bkcore_last_hip_error",
            "bkcore_error_string", "bkcore_abi_version")
 
@@ -101,6 +102,11 @@ def load():
     L.bkcore_woodbury_correct.restype = i32
     L.bkcore_woodbury_workspace_bytes.argtypes = [i64, i64, i64]
     L.bkcore_woodbury_workspace_bytes.restype = ctypes.c_size_t
+    L.bkcore_get_diag_complex.argtypes = [vp, i64, vp, i64, vp, i64, vp, f32, f32, i64, i64, vp, vp, ctypes.c_size_t,
+                                          ctypes.c_uint, vp]
+    L.bkcore_get_diag_complex.restype = i32
+    L.bkcore_get_diag_complex_workspace_bytes.argtypes = [i64, i64]
+    L.bkcore_get_diag_complex_workspace_bytes.restype = ctypes.c_size_t
     L.bkcore_max_seq_len.restype = i64
     L.bkcore_forward_plan.argtypes = [i64, i64, i32, ctypes.c_uint, i32, ctypes.POINTER(ctypes.c_int)]
     L.bkcore_forward_plan.restype = i32

@@ -128,7 +128,9 @@ def _check_batch(B: int, b: torch.Tensor, c: torch.Tensor):
 
 def _prep_inputs(a, b, c):
     if a.is_complex() or b.is_complex() or c.is_complex():
-        raise TypeError("bkcore: complex a/b/c are not supported by the HIP kernels (real dtypes only)")
+        # as in the reference, whose input clamp (bk_core.py:256-258) is not defined for complex tensors
+        raise TypeError("bkcore: the operator takes real he_diag / h0_super / h0_sub (its input clamp is not defined "
+                        "for complex tensors); vmapped_get_diag / get_tridiagonal_inverse_diagonal accept complex ones")
     if not a.is_cuda:
         raise RuntimeError("bkcore: tensors must be on a ROCm device (no CPU path; use the oracle for CPU checks)")
     dt = a.dtype
@@ -478,9 +480,46 @@ def analytic_rows_recomputed() -> int:
     return int(ws[off: off + 4 * B].view(torch.int32).ne(0).sum().item())
 
 
+_ws_complex = {}              # (device index, stream) -> workspace of the complex-operand kernel
+
+
+def _get_diag_complex(a, b, c, z, phi_exact: bool):
+    """The raw resolvent diagonal for complex operands: any of a, b, c complex (the rest is converted, as the reference
+    converts every operand to complex128, bk_core.py:45-47; the kernel reads complex64)."""
+    L = _lib.load()
+    if not a.is_cuda:
+        raise RuntimeError("bkcore: tensors must be on a ROCm device (no CPU path; use the oracle for CPU checks)")
+    if b.device != a.device or c.device != a.device:
+        raise RuntimeError("bkcore: a, b, c must be on the same device")
+    a, b, c = (x.detach().to(torch.complex64).resolve_conj().resolve_neg() for x in (a, b, c))
+    B, N = a.shape
+    nb = max(N - 1, 0)
+    G = torch.empty((B, N), dtype=torch.complex64, device=a.device)
+    if B == 0 or N == 0:
+        return G
+    _check_batch(B, b, c)
+    a, pa, lda = _rows(a, N, "a")
+    b, pb, ldb = _rows(b, nb, "b")
+    c, pc, ldc = _rows(c, nb, "c")
+    dev = a.device
+    with _on_device(dev):
+        stream = torch.cuda.current_stream().cuda_stream
+        zkeep, pz, zre, zim = _prep_z(z, dev)
+        need = int(L.bkcore_get_diag_complex_workspace_bytes(B, N))
+        ws = _cached_workspace(_ws_complex, dev, stream, need)
+        rc = L.bkcore_get_diag_complex(pa, lda, pb if nb else None, ldb, pc if nb else None, ldc, pz, zre, zim, B, N,
+                                       G.data_ptr(), ws.data_ptr(), need, _lib.FLAG_PHI_EXACT if phi_exact else 0,
+                                       stream)
+    _lib.check(rc, "bkcore_get_diag_complex")
+    del zkeep
+    return G
+
+
 def vmapped_get_diag(a, b, c, z):
     """Batched diag((T - zI)^-1): (B,N),(B,N-1),(B,N-1),z -> (B,N) complex64.  No input clamps
-    (reference bk_core.py:214-216)."""
+    (reference bk_core.py:214-216).  Complex a, b or c are accepted as in the reference (bk_core.py:45-47)."""
+    if a.is_complex() or b.is_complex() or c.is_complex():
+        return _get_diag_complex(a, b, c, z, BKCoreFunction.PHI_K_INDEX == "exact")
     return bk_forward(a, b, c, z, raw=True, phi_exact=(BKCoreFunction.PHI_K_INDEX == "exact"),
                       want_features=False)[1]
 

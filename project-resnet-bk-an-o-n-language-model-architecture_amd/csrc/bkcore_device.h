@@ -51,6 +51,22 @@ __device__ __forceinline__ float2 cmad(float2 acc, float2 p, float2 q) {
 __device__ __forceinline__ float2 rstep(float2 al, float ka, float2 x, float2 p) {
   return make_float2(fmaf(al.x, x.x, fmaf(-al.y, x.y, -ka * p.x)), fmaf(al.x, x.y, fmaf(al.y, x.x, -ka * p.y)));
 }
+// The type of k = b c.  The operator's operands are real; the second compilation of the scan kernel
+// (bkcore_complex.hip: complex he_diag / h0_super / h0_sub for the raw resolvent diagonal, which the reference
+// accepts by converting every operand to complex128, bk_core.py:45-47) carries a complex k through the same code.
+#ifdef BK_COMPLEX_BUILD
+typedef float2 KT;
+__device__ __forceinline__ float2 rstep(float2 al, float2 ka, float2 x, float2 p) {
+  const float2 kp = cmul(ka, p);
+  return make_float2(fmaf(al.x, x.x, fmaf(-al.y, x.y, -kp.x)), fmaf(al.x, x.y, fmaf(al.y, x.x, -kp.y)));
+}
+__device__ __forceinline__ float2 kscale(float2 k, float w) { return make_float2(k.x * w, k.y * w); }
+__device__ __forceinline__ float2 kzero() { return make_float2(0.0f, 0.0f); }
+#else
+typedef float KT;
+__device__ __forceinline__ float kscale(float k, float w) { return k * w; }
+__device__ __forceinline__ float kzero() { return 0.0f; }
+#endif
 // p / q
 __device__ __forceinline__ float2 cdiv(float2 p, float2 q) {
   const float inv = __builtin_amdgcn_rcpf(fmaf(q.x, q.x, q.y * q.y));
@@ -188,7 +204,10 @@ struct Shared {
   union {
     struct {
       float a_s[A_PAD];       // staged diagonal, index idx + idx/32
-      float k_s[A_PAD + 4];   // staged k_{i-1} = b_{i-1} c_{i-1} for i = chunk_base .. chunk_base+CHUNK (CHUNK+1 values)
+#ifdef BK_COMPLEX_BUILD
+      float a_i[A_PAD];       // its imaginary part
+#endif
+      KT k_s[A_PAD + 4];      // staged k_{i-1} = b_{i-1} c_{i-1} for i = chunk_base .. chunk_base+CHUNK (CHUNK+1 values)
     } in;
     float2 out_s[O_PAD];      // G of one chunk, index idx + idx/16, for coalesced stores
   } u;

@@ -31,7 +31,9 @@
 #include "bkcore_device.h"
 
 // Device memory of bkcore_forward_noalloc (one copy per GPU the library runs on, held until the process ends).
+#ifndef BK_COMPLEX_BUILD
 static __device__ __align__(256) unsigned char bk_static_scratch[256 + BKCORE_NOALLOC_MAX_WORKSPACE];
+#endif
 
 namespace {
 
@@ -41,7 +43,7 @@ namespace {
 // elements plus one more (k of the lane's last element); KO selects which one a step uses.
 
 // One more element folded into the running product A <- M(al, k) * A.
-__device__ __forceinline__ void agg_step(Mat &A, float2 al, float k) {
+__device__ __forceinline__ void agg_step(Mat &A, float2 al, KT k) {
   const float2 na = rstep(al, k, A.a, A.c);
   const float2 nb = rstep(al, k, A.b, A.d);
   A.c = A.a;
@@ -53,7 +55,7 @@ __device__ __forceinline__ void agg_step(Mat &A, float2 al, float k) {
 // Pass 1: product of the lane's E transfer matrices (linear recurrence, plain k) in processing order.
 // Renormalised every 4 elements: one step grows an entry by at most |alpha| + |k| (2^7.7 for clamped inputs).
 template <bool REV, bool TAIL, int KO>
-__device__ __forceinline__ Mat lane_aggregate(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask) {
+__device__ __forceinline__ Mat lane_aggregate(const float2 (&al)[E], const KT (&kw)[E + 1], unsigned vmask) {
   Mat A = mat_identity();
 #pragma unroll
   for (int j = 0; j < E; ++j) {
@@ -68,8 +70,8 @@ __device__ __forceinline__ Mat lane_aggregate(const float2 (&al)[E], const float
 // pass-1 state gives d_p and so the wall factor; k2 = k * w is recorded and folded straight into the pass-2
 // product of the lane.
 template <bool REV, bool TAIL, int KO>
-__device__ __forceinline__ Mat wall_and_aggregate(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask,
-                                                  Vec x, float (&k2)[E]) {
+__device__ __forceinline__ Mat wall_and_aggregate(const float2 (&al)[E], const KT (&kw)[E + 1], unsigned vmask,
+                                                  Vec x, KT (&k2)[E]) {
   Mat A = mat_identity();
   float l0 = log2_norm2(x.x0);
   float l1 = log2_norm2(x.x1);
@@ -77,7 +79,7 @@ __device__ __forceinline__ Mat wall_and_aggregate(const float2 (&al)[E], const f
   for (int j = 0; j < E; ++j) {
     const int ei = REV ? E - 1 - j : j;
     const float d = LN2_HALF * (l1 - l0);  // ln|prev2| - ln|prev|
-    const float kk = kw[ei + KO] * wall_corr(d);
+    const KT kk = kscale(kw[ei + KO], wall_corr(d));
     k2[ei] = kk;
     if (!TAIL || ((vmask >> ei) & 1u)) {
       const float2 y = rstep(al[ei], kw[ei + KO], x.x0, x.x1);
@@ -107,7 +109,7 @@ __device__ __forceinline__ Mat wall_and_aggregate(const float2 (&al)[E], const f
 // The estimate is checked afterwards against the exact pass-2 state (ratio_differs); a row with any mismatch is
 // recomputed by the two-scan path in the second launch.
 template <bool REV, bool TAIL, int KO>
-__device__ __forceinline__ Vec warm_run(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask) {
+__device__ __forceinline__ Vec warm_run(const float2 (&al)[E], const KT (&kw)[E + 1], unsigned vmask) {
   Vec x = vec_start();
 #pragma unroll
   for (int j = 0; j < E; ++j) {
@@ -123,7 +125,7 @@ __device__ __forceinline__ Vec warm_run(const float2 (&al)[E], const float (&kw)
 }
 
 template <bool REV, bool TAIL, int KO>
-__device__ __forceinline__ Vec estimate_incoming(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask,
+__device__ __forceinline__ Vec estimate_incoming(const float2 (&al)[E], const KT (&kw)[E + 1], unsigned vmask,
                                                  Shared &sh, const ScanCtx &ctx) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -160,7 +162,7 @@ __device__ __forceinline__ bool ratio_differs(const Vec &est, const Vec &x) {
 // of the LDS output tile (`om`, consecutive), where the epilogue later replaces each by G in place; exponents
 // are shared by element pairs and stay in registers.
 template <bool TAIL, bool SAVE>
-__device__ __forceinline__ void theta_lane(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask, Vec x,
+__device__ __forceinline__ void theta_lane(const float2 (&al)[E], const KT (&kw)[E + 1], unsigned vmask, Vec x,
                                            float2 *__restrict__ om, int (&oe)[E / 2], float2 *__restrict__ save_r) {
   float2 u0 = x.x0, u1 = x.x1;  // linear chain
   float l0 = log2_norm2(u0);
@@ -170,7 +172,7 @@ __device__ __forceinline__ void theta_lane(const float2 (&al)[E], const float (&
     om[j] = x.x0;
     if ((j & 1) == 0) oe[j >> 1] = x.e;
     const float d = LN2_HALF * (l1 - l0);
-    const float kk = kw[j] * wall_corr(d);
+    const KT kk = kscale(kw[j], wall_corr(d));
     if (!TAIL || ((vmask >> j) & 1u)) {
       const float2 yu = rstep(al[j], kw[j], u0, u1);
       const float2 y = rstep(al[j], kk, x.x0, x.x1);
@@ -241,6 +243,65 @@ __device__ __forceinline__ Vec block_exclusive(Mat A, int which, Shared &sh, Sca
 // FULL: every index idx < CHUNK of all three operands lies inside the row (interior chunks): no bounds logic.
 // Otherwise the loads use clamped (always valid) indices and out-of-row values are replaced afterwards.
 // Returns bit0: NaN seen in a, bit1: NaN seen in b or c.
+#ifdef BK_COMPLEX_BUILD
+// Complex operands (interleaved complex64), raw semantics only: nothing is clamped or repaired (bk_core.py:42-56).
+template <typename TIn, bool FULL>
+__device__ __forceinline__ unsigned stage_chunk(const TIn *__restrict__ a, const TIn *__restrict__ b,
+                                                const TIn *__restrict__ c, long base, const RowCfg &cfg, Shared &sh) {
+  static_assert(std::is_same<TIn, float2>::value, "the complex build takes complex64 operands");
+  const int t = threadIdx.x;
+  const float2 *__restrict__ ap = a + base;
+  const int a_hi = (int)min((long)CHUNK, cfg.N - base) - 1;
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const int idx = t + j * T;
+    float2 v = ap[FULL ? idx : min(idx, a_hi)];
+    if (!FULL && idx > a_hi) v = make_float2(1.0f, 0.0f);
+    sh.u.in.a_s[pad32(idx)] = v.x;
+    sh.u.in.a_i[pad32(idx)] = v.y;
+  }
+  const int k_lo = base == 0 ? 1 : 0;
+  const int k_hi = (int)min((long)CHUNK, cfg.N - 1 - base);
+  if (FULL || k_hi >= k_lo) {
+    const float2 *__restrict__ bp = b + (base - 1);
+    const float2 *__restrict__ cp = c + (base - 1);
+#pragma unroll
+    for (int j = 0; j <= E; ++j) {
+      if (j < E || t == 0) {
+        const int idx = t + j * T;   // j == E: the one extra value k_s[CHUNK], by thread 0
+        const int ii = min(max(idx, k_lo), k_hi);
+        const bool ok = idx >= k_lo && idx <= k_hi;
+        sh.u.in.k_s[pad32(idx)] = ok ? cmul(bp[ii], cp[ii]) : kzero();
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j <= E; ++j)
+      if (j < E || t == 0) sh.u.in.k_s[pad32(t + j * T)] = kzero();
+  }
+  return 0u;
+}
+
+__device__ __forceinline__ void fetch_elems(const Shared &sh, long base, int seg, const RowCfg &cfg, float2 (&al)[E],
+                                            KT (&kw)[E + 1], unsigned &vmask) {
+#pragma unroll
+  for (int e = 0; e <= E; ++e) kw[e] = sh.u.in.k_s[pad32(seg * E + e)];
+  const long first = base + (long)seg * E;
+  const long left = cfg.N - first;
+  vmask = left >= E ? ((1u << E) - 1u) : (left <= 0 ? 0u : ((1u << (int)left) - 1u));
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    // reg(a - z) = x + 1e-3 x / |x|, and x + 1e-3 where |x| < 1e-12 (bk_core.py:78-94)
+    const float xr = sh.u.in.a_s[pad32(seg * E + e)] - cfg.z.x;
+    const float xi = sh.u.in.a_i[pad32(seg * E + e)] - cfg.z.y;
+    const float n = fmaf(xr, xr, xi * xi);
+    float f = fmaf(1e-3f, __builtin_amdgcn_rsqf(n), 1.0f);
+    float add = 0.0f;
+    if (!(n >= 1e-24f)) { f = 1.0f; add = 1e-3f; }
+    al[e] = make_float2(fmaf(xr, f, add), xi * f);
+  }
+}
+#else
 template <typename TIn, bool FULL>
 __device__ __forceinline__ unsigned stage_chunk(const TIn *__restrict__ a, const TIn *__restrict__ b,
                                                 const TIn *__restrict__ c, long base, const RowCfg &cfg, Shared &sh) {
@@ -344,7 +405,7 @@ __device__ __forceinline__ unsigned stage_chunk(const TIn *__restrict__ a, const
 // `seg` is the 16-element segment of the chunk this thread owns (thread t in sweep A, T-1-t in sweep B, so that
 // the phi scan also runs over ascending threads).
 __device__ __forceinline__ void fetch_elems(const Shared &sh, long base, int seg, const RowCfg &cfg, float2 (&al)[E],
-                                            float (&kw)[E + 1], unsigned &vmask) {
+                                            KT (&kw)[E + 1], unsigned &vmask) {
 #pragma unroll
   for (int e = 0; e <= E; ++e) kw[e] = sh.u.in.k_s[pad32(seg * E + e)];
   const long first = base + (long)seg * E;
@@ -371,6 +432,8 @@ __device__ __forceinline__ void fetch_elems(const Shared &sh, long base, int seg
   }
 }
 
+#endif  // BK_COMPLEX_BUILD (staging)
+
 // ---- the forward kernel -------------------------------------------------------------------------------------
 // lane-state storage: 5 floats per (chunk, thread), laid out [chunk][field][thread]
 __device__ __forceinline__ void put_state(float *st, int ch, int seg, const Vec &x) {
@@ -395,8 +458,8 @@ __device__ __forceinline__ Vec get_state(const float *st, int ch, int seg) {
 // Pass 1 + pass 2 of one chunk in one direction: fills k2 (wall-corrected k per element) and returns the lane's
 // exact incoming pass-2 state.  FAST: pass 1 by the verified warm-up estimate instead of a product + scan.
 template <bool FAST, bool REV, bool TAIL, int KO>
-__device__ __forceinline__ Vec two_pass(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask,
-                                        float (&k2)[E], Shared &sh, ScanCtx &ctx, bool &bad) {
+__device__ __forceinline__ Vec two_pass(const float2 (&al)[E], const KT (&kw)[E + 1], unsigned vmask,
+                                        KT (&k2)[E], Shared &sh, ScanCtx &ctx, bool &bad) {
   Vec est;
   if (FAST) {
     est = estimate_incoming<REV, TAIL, KO>(al, kw, vmask, sh, ctx);
@@ -412,11 +475,11 @@ __device__ __forceinline__ Vec two_pass(const float2 (&al)[E], const float (&kw)
 }
 
 template <bool FAST, bool TAIL, int KO_PHI, bool SAVE>
-__device__ __forceinline__ void sweepB_chunk(const float2 (&al)[E], const float (&kw)[E + 1], unsigned vmask,
+__device__ __forceinline__ void sweepB_chunk(const float2 (&al)[E], const KT (&kw)[E + 1], unsigned vmask,
                                              const Vec &xt, float2 inv_det, int e_det, Shared &sh, ScanCtx &ctx,
                                              int seg, bool &bad, float2 *__restrict__ save_r,
                                              float2 *__restrict__ save_s) {
-  float k2[E];
+  KT k2[E];
   Vec x = two_pass<FAST, true, TAIL, KO_PHI>(al, kw, vmask, k2, sh, ctx, bad);
   // theta of the lane's elements into the lane's slots of the output tile.  (All reads of the staged inputs
   // happened before the scans' barriers, so the tile may overwrite them; each slot is touched by this thread only.)
@@ -475,13 +538,13 @@ __device__ __forceinline__ void sweepA_range(const TIn *__restrict__ a, const TI
     constexpr bool FULL = decltype(full)::value, TAIL = decltype(tail)::value;
     const long base = (long)ch * CHUNK;
     float2 al[E];
-    float kw[E + 1];
+    KT kw[E + 1];
     unsigned vmask;
     __syncthreads();  // previous chunk's LDS reads done
     seen |= stage_chunk<TIn, FULL>(a, b, c, base, cfg, sh);
     __syncthreads();
     fetch_elems(sh, base, t, cfg, al, kw, vmask);
-    float k2[E];
+    KT k2[E];
     const Vec x = two_pass<FAST, false, TAIL, 0>(al, kw, vmask, k2, sh, ctx, bad);
     put_state(st, ch, t, x);
   };
@@ -510,7 +573,7 @@ __device__ __forceinline__ void sweepB_range(const TIn *__restrict__ a, const TI
     constexpr bool FULL = decltype(full)::value, TAIL = decltype(tail)::value;
     const long base = (long)ch * CHUNK;
     float2 al[E];
-    float kw[E + 1];
+    KT kw[E + 1];
     unsigned vmask;
     __syncthreads();  // previous chunk's out_s reads done (and lane states visible)
     stage_chunk<TIn, FULL>(a, b, c, base, cfg, sh);
@@ -697,6 +760,7 @@ __global__ __launch_bounds__(T, BK_WAVES_PER_SIMD) void bk_forward_kernel(
   if (second) state_release(state, true, (flags & BKCORE_FLAG_ADAPTIVE) != 0);
 }
 
+#ifndef BK_COMPLEX_BUILD
 // ---- long rows, few of them: several workgroups per row --------------------------------------------------------
 // With B below the number of workgroups the chip holds, a row is cut into S segments of `seg_ch` chunks and each
 // (row, segment) gets its own workgroup.  A segment cannot know the state entering it, but it does not need to:
@@ -1887,7 +1951,7 @@ int bkcore_forward_plan(int64_t B, int64_t N, int in_dtype, unsigned flags, int 
 }
 int bkcore_last_hip_error(void) { return g_last_hip_error; }
 void bkcore_internal_set_hip_error(int code) { g_last_hip_error = code; }
-int bkcore_abi_version(void) { return 17; }
+int bkcore_abi_version(void) { return 18; }
 
 const char *bkcore_error_string(int code) {
   switch (code) {
@@ -1902,3 +1966,48 @@ const char *bkcore_error_string(int code) {
 }
 
 }  // extern "C"
+
+#else  // BK_COMPLEX_BUILD: the scan kernel above with a complex k, and its one entry point
+
+}  // namespace
+
+extern "C" {
+
+// Lane states of the complex kernel (its chunks are half as long as the main build's).
+size_t bkcore_get_diag_complex_workspace_bytes(int64_t B, int64_t N) {
+  if (B <= 0 || N <= 0) return 0;
+  return rowflag_bytes(B) + lane_state_bytes(B, N);
+}
+
+int bkcore_get_diag_complex(const float *a, int64_t lda, const float *b, int64_t ldb, const float *c, int64_t ldc,
+                            const float *z_dev, float z_re, float z_im, int64_t B, int64_t N, float *G, void *workspace,
+                            size_t workspace_bytes, unsigned flags, void *stream) {
+  if (B < 0 || N < 0 || lda < 0 || ldb < 0 || ldc < 0) return BKCORE_EINVAL;
+  if (flags & ~(unsigned)BKCORE_FLAG_PHI_EXACT) return BKCORE_EINVAL;
+  if (B == 0 || N == 0) return BKCORE_OK;
+  if (!a || !G || (N > 1 && (!b || !c))) return BKCORE_EINVAL;
+  if (N > MAX_N) return BKCORE_ETOOLONG;
+  if (B > 2147483647LL) return BKCORE_EINVAL;
+  const size_t need = bkcore_get_diag_complex_workspace_bytes(B, N);
+  if (!workspace || workspace_bytes < need) return BKCORE_EWORKSPACE;
+  const unsigned kflags = flags | BKCORE_FLAG_RAW;
+  const hipStream_t s = (hipStream_t)stream;
+  // one launch of the two-scan form (no assumption about the input, nothing to verify afterwards)
+#define BK_LAUNCH_C(PHI)                                                                                              \
+  hipLaunchKernelGGL((bk_forward_kernel<float2, PHI, false, false>), dim3((unsigned)B), dim3(T), 0, s,                \
+                     (const float2 *)a, (long)lda, (const float2 *)b, (long)ldb, (const float2 *)c, (long)ldc, z_dev, \
+                     z_re, z_im, (long)B, (long)N, (float2 *)G, (float2 *)nullptr, (char *)workspace, (int *)nullptr, \
+                     0, kflags, __builtin_huge_valf(), (float2 *)nullptr, (float2 *)nullptr)
+  if (flags & BKCORE_FLAG_PHI_EXACT) BK_LAUNCH_C(true);
+  else BK_LAUNCH_C(false);
+#undef BK_LAUNCH_C
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    bkcore_internal_set_hip_error((int)err);
+    return BKCORE_ELAUNCH;
+  }
+  return BKCORE_OK;
+}
+
+}  // extern "C"
+#endif  // BK_COMPLEX_BUILD
