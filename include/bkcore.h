@@ -358,7 +358,8 @@ int64_t bkcore_max_seq_len(void);
  * if there is no device or no answer: exactly what the dispatch does); cus > 0: what-if for a GPU with that many
  * compute units holding 3 workgroups each (2 for 16-bit operands).  Returns pieces per row: 1 = one workgroup per row
  * (rows that fill the GPU evenly: between 0.95 and 1 times as many rows as it holds workgroups, or more than 1.85
- * times; rows of one or two chunks of 4096); the number of chunks of the row = one workgroup per chunk, the running
+ * times; 16-bit operands whose rows fill rounds of 2 workgroups per compute unit to 90 % or exactly; rows of one or
+ * two chunks of 4096); the number of chunks of the row = one workgroup per chunk, the running
  * product handed from chunk to chunk inside the launch (every other shape: fewer rows, or a ragged second round); 2 =
  * two units a row on a grid that must be resident at once (float32 / float64 operands between 1.24 and 1.37 times as
  * many rows as places, e.g. 1024 rows on 256 CUs; never with BKCORE_FLAG_WHOLE_ROWS).

@@ -1465,7 +1465,8 @@ inline void relay_plan(int64_t B, int64_t N, int chunk, int wgs_per_cu, unsigned
 //   chunks       one workgroup per chunk with the look-back hand-over (mode 4).  Best whenever whole rows would leave
 //                CUs unevenly or thinly occupied: B <= 0.95 P (129 rows x 32768: 0.064 -> 0.033 ms; 600 rows: 0.119 ->
 //                0.102 ms; 129 rows x 131072: 0.238 -> 0.090 ms) and P < B < 1.85 P (1300 rows: 0.205 -> 0.200 ms;
-//                16-bit operands, whose whole rows run two per CU: 0.236 -> 0.200 ms).
+//                16-bit operands, whose whole rows run two per CU: 0.236 -> 0.200 ms) -- except 16-bit operands whose
+//                whole rows fill their rounds of 2 x CUs (see below).
 //   units        rows in two units on a grid of one workgroup per place (mode 3): 4 % ahead of chunks between 1.24 P
 //                and 1.37 P for float32 / float64 operands (1024 rows: 0.155 against 0.162 ms) and nowhere else; needs
 //                its grid resident at once, so not with BKCORE_FLAG_WHOLE_ROWS.
@@ -1496,7 +1497,15 @@ inline int ratio_form_plan(int64_t B, int64_t N, int in_dtype, bool phi_exact, u
   }
   if (force_chunks > 0 && chunks_possible) return FORM_CHUNKS;
   if (!chunks_possible) return FORM_WHOLE;
-  const int64_t P = (int64_t)(long_rows ? 2 : 3) * (cus_given > 0 ? cus_given : device_cu_count());
+  const int64_t cus = cus_given > 0 ? cus_given : device_cu_count();
+  const int64_t P = (int64_t)(long_rows ? 2 : 3) * cus;
+  if (sixteen) {
+    // whole rows of 16-bit operands run two per CU: with their last round full, or nearly, they are ahead of the chunk
+    // form (bf16, N = 32768: 512 rows 0.088 against 0.091 ms, 980 rows 0.159 / 0.163, 1024 rows 0.162 / 0.169, 1536 rows
+    // 0.225 / 0.237; but 560 rows 0.124 / 0.099, 1080 rows 0.193 / 0.177)
+    const int64_t Pw = 2 * cus, fill = B % Pw;
+    if (10 * B >= 9 * Pw && (fill == 0 || 10 * fill >= 9 * Pw)) return FORM_WHOLE;
+  }
   if (nch >= 3 && 20 * B <= 19 * P) return FORM_CHUNKS;
   if (nch >= 4 && B > P && 20 * B < 37 * P) {
     if (per_cu > 0 && !sixteen && 100 * B >= 124 * P && 100 * B <= 137 * P) {

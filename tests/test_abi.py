@@ -116,8 +116,11 @@ def test_forward_plan_policy():
     assert plan(1536, 32768) == (1, 2) and plan(2000, 32768) == (1, 2) and plan(8192, 32768) == (1, 2)
     assert plan(1024, 3 * 4096) == (1, 2)           # fewer than four chunks and more rows than places: whole rows
     assert plan(600, 3 * 4096) == (3, 2) and plan(600, 2 * 4096) == (1, 2)
-    assert plan(1024, 32768, _lib.BF16) == (8, 2)   # 16-bit operands: chunks wherever units would be considered
-    assert plan(600, 32768, _lib.BF16) == (8, 2)
+    # 16-bit operands: whole rows (two per CU, 512 places) when their last round is full or nearly so, chunks otherwise
+    assert plan(1024, 32768, _lib.BF16) == (1, 2) and plan(512, 32768, _lib.BF16) == (1, 2)
+    assert plan(980, 32768, _lib.BF16) == (1, 2) and plan(1536, 32768, _lib.F16) == (1, 2)
+    assert plan(600, 32768, _lib.BF16) == (8, 2) and plan(1080, 32768, _lib.BF16) == (8, 2)
+    assert plan(900, 32768, _lib.BF16) == (8, 2) and plan(400, 32768, _lib.BF16) == (8, 2)
     assert plan(1024, 32768, flags=_lib.FLAG_ADAPTIVE) == (1, 2)
     assert plan(1024, 1 << 18) == (1, 2)            # rows beyond 49152 elements run in double, two workgroups per CU
     assert plan(600, 1 << 18) == (64, 2)
