@@ -81,6 +81,11 @@ def _worker(rank, world, port, B, N, out_dir):
             np.save(os.path.join(out_dir, "ok.npy"), np.array([np.array_equal(G.numpy(), G_full)]))
     finally:
         dist.destroy_process_group()
+    # results are on disk and the group is gone: end the rank here rather than in interpreter shutdown, where a rank
+    # that has used gloo occasionally aborts in a library thread's destructor
+    import sys
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(0)
 
 
 def test_two_rank_sharded_equals_unsharded(tmp_path):

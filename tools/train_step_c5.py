@@ -26,6 +26,9 @@ def main(argv=None, operator=None):
                     help="capture the whole step (forward, backward, clip, AdamW) in one HIP graph and replay it (1 GPU)")
     ap.add_argument("--hybrid", action="store_true", help="G_ii gates the mixing path (use_hybrid_attention)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"])
+    ap.add_argument("--force-dist", action="store_true",
+                    help="a single rank also initialises the process group and wraps the model in DDP (rehearses the "
+                         "RCCL path on a one-GPU machine; launch through torch.distributed.run)")
     ap.add_argument("--vocab", type=int, default=50257)
     ap.add_argument("--d-model", type=int, default=256)
     ap.add_argument("--layers", type=int, default=4)
@@ -40,7 +43,8 @@ def main(argv=None, operator=None):
     sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     if on_gpu:
         torch.cuda.set_device(device)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         import torch.distributed as dist
         if on_gpu:
             dist.init_process_group("nccl", device_id=device)
@@ -52,7 +56,7 @@ def main(argv=None, operator=None):
                             fused=args.fused, hybrid=args.hybrid).to(device)
     if operator is not None:
         model.set_bk_core(operator)
-    if world > 1:
+    if dist_on:
         # hybrid: output_proj and bk_scale of each layer take no part in the step (as in the reference layer)
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index] if on_gpu else None,
                                                           find_unused_parameters=args.hybrid)
@@ -80,17 +84,17 @@ def main(argv=None, operator=None):
             return static_loss
     for _ in range(args.warmup):
         loss = step()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -99,10 +103,13 @@ def main(argv=None, operator=None):
         line = ({"metric": "resnet_bk_small_lm_train_tokens_per_sec", "value": world * args.batch * n_seq * args.steps / dt,
                           "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
                           "final_loss": float(loss), "fused_layer": bool(args.fused), "hybrid": bool(args.hybrid), "hip_graph": bool(args.graph),
-                 "device": args.device, "config": {"workload": f"phase7_small dims: d_model {args.d_model}, {args.layers} layers, n_seq {n_seq}, "
+                 "device": args.device, "ddp": bool(dist_on), "config": {"workload": f"phase7_small dims: d_model {args.d_model}, {args.layers} layers, n_seq {n_seq}, "
                           f"batch {args.batch}/GPU, vocab {args.vocab}, AdamW 1e-4, clip 1.0; dummy tokens", "parallelism": f"dp{world}"}})
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
+        # every rank idle and the DDP wrapper (its reducer holds the process group) gone before the group is torn down
+        dist.barrier()
+        del step, opt, model
         dist.destroy_process_group()
     return line
 
